@@ -1,0 +1,150 @@
+"""Generate tests/golden/*.npz by running the REAL reference model -- build container only.
+
+TEST INFRASTRUCTURE.  Imports /root/reference/model/unet.py (read-only, never copied), loads
+the seeded checkpoint of oracle.unet_oracle.make_seeded_state_dict into it with
+load_state_dict (strict), puts it in .eval() like inference.py:97 does, and records
+inputs + expected outputs as small fixtures.  The reference cannot travel to the GPU box;
+these vectors (data only) do.
+
+    python oracle/gen_golden.py            # writes tests/golden/
+"""
+from __future__ import annotations
+
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from oracle import unet_oracle as O  # noqa: E402
+
+REF_DIR = "/root/reference/model"
+GOLD = os.path.join(ROOT, "tests", "golden")
+WEIGHT_SEED = 1234
+
+
+def strided_sample(t: torch.Tensor, n: int = 2048):
+    flat = t.reshape(-1)
+    step = max(1, flat.numel() // n)
+    idx = torch.arange(0, flat.numel(), step)[:n]
+    return idx.numpy().astype(np.int64), flat[idx].numpy().astype(np.float32)
+
+
+def main():
+    sys.path.insert(0, REF_DIR)
+    from unet import FrameInterpolationUNet  # the reference class (unet.py:97)
+
+    torch.manual_seed(0)
+    torch.set_num_threads(8)
+    os.makedirs(GOLD, exist_ok=True)
+    sd = O.make_seeded_state_dict(WEIGHT_SEED)
+    model = FrameInterpolationUNet(bilinear=True)
+    missing = model.load_state_dict(sd, strict=True)
+    print("load_state_dict:", missing)
+    model.eval()
+    # the schema itself is a pinned fact: names, shapes, dtypes, order
+    ref_sd = model.state_dict()
+    schema = [(k, tuple(v.shape), str(v.dtype)) for k, v in ref_sd.items()]
+    assert [s[0] for s in schema] == [s[0] for s in O.state_dict_schema()]
+    with open(os.path.join(GOLD, "state_dict_schema.txt"), "w") as f:
+        for k, shp, dt in schema:
+            f.write(f"{k}\t{','.join(map(str, shp))}\t{dt}\n")
+    nparams = sum(p.numel() for p in model.parameters())
+    print("params:", nparams)
+
+    # ---- whole-net outputs, stored in full (small sizes) --------------------------------
+    full_cases = [  # name, seed, B, H, W
+        ("b1_32x48", 11, 1, 32, 48),
+        ("b2_64x64", 12, 2, 64, 64),
+        ("b1_17x31", 13, 1, 17, 31),     # odd sizes: floor-pool + asymmetric pad (unet.py:49-53)
+        ("b1_16x16", 14, 1, 16, 16),     # minimum legal size
+        ("b1_135x240", 15, 1, 135, 240),  # 1080p/8: same pad pattern as 1080p (135->67->...)
+        ("b1_256x256", 0, 1, 256, 256),  # BASELINE config 1
+    ]
+    for name, seed, b, h, w in full_cases:
+        f1, f2 = O.make_frames(seed, b, h, w)
+        with torch.no_grad():
+            out = model(f1, f2)
+        mine = O.unet_forward(sd, f1, f2)
+        print(f"{name}: out std {out.std():.4f} min {out.min():.3f} max {out.max():.3f} "
+              f"|restatement-ref| {float((mine - out).abs().max()):.3e}")
+        np.savez_compressed(
+            os.path.join(GOLD, f"out_{name}.npz"),
+            seed=seed, weight_seed=WEIGHT_SEED,
+            frame1=f1.numpy(), frame2=f2.numpy(), out=out.numpy(),
+        )
+
+    # ---- per-layer activations for one small pair (hooks on the reference modules) -------
+    f1, f2 = O.make_frames(11, 1, 32, 48)
+    acts = {}
+
+    def hook(name):
+        def fn(_m, _inp, outp):
+            acts[name] = outp.detach().clone()
+        return fn
+
+    handles = []
+    for mod_name, mod in model.named_modules():
+        # the ReLU after each BN is inplace, so the BN module's output tensor as seen after the
+        # forward already holds conv->BN->ReLU; hook the ReLUs (indices 2 and 5) explicitly.
+        if mod_name.endswith("double_conv.2") or mod_name.endswith("double_conv.5"):
+            conv_idx = "0" if mod_name.endswith(".2") else "3"
+            handles.append(mod.register_forward_hook(
+                hook(mod_name.rsplit(".", 1)[0] + "." + conv_idx)))
+        if mod_name.endswith("maxpool_conv.0"):
+            handles.append(mod.register_forward_hook(
+                hook(mod_name.split(".maxpool_conv")[0] + ".pool")))
+        if mod_name == "unet.outc":
+            handles.append(mod.register_forward_hook(hook("unet.outc")))
+    with torch.no_grad():
+        out = model(f1, f2)
+    for hd in handles:
+        hd.remove()
+    taps = {}
+    O.unet_forward(sd, f1, f2, taps)
+    layer_fix = {}
+    for k, v in acts.items():
+        assert k in taps, k
+        d = float((taps[k] - v).abs().max())
+        idx, vals = strided_sample(v, 1024)
+        layer_fix[f"{k}|idx"] = idx
+        layer_fix[f"{k}|val"] = vals
+        layer_fix[f"{k}|sum"] = np.float64(v.double().sum().item())
+        layer_fix[f"{k}|abssum"] = np.float64(v.double().abs().sum().item())
+        layer_fix[f"{k}|shape"] = np.array(v.shape, dtype=np.int64)
+        print(f"  layer {k:42s} shape {tuple(v.shape)} |restatement-ref| {d:.2e}")
+    np.savez_compressed(os.path.join(GOLD, "layers_b1_32x48.npz"),
+                        frame1=f1.numpy(), frame2=f2.numpy(), **layer_fix)
+
+    # ---- 1080p: strided sample + float64 sums only ---------------------------------------
+    f1, f2 = O.make_frames(16, 1, 1080, 1920)
+    t0 = time.time()
+    with torch.no_grad():
+        out = model(f1, f2)
+    print(f"1080p reference forward: {time.time() - t0:.1f} s")
+    idx, vals = strided_sample(out, 4096)
+    u8 = O.postprocess_tensor(out)
+    np.savez_compressed(
+        os.path.join(GOLD, "out_b1_1080x1920_sample.npz"),
+        seed=16, weight_seed=WEIGHT_SEED, idx=idx, val=vals,
+        sum=np.float64(out.double().sum().item()),
+        abssum=np.float64(out.double().abs().sum().item()),
+        u8_hist=np.bincount(u8.reshape(-1), minlength=256).astype(np.int64),
+    )
+
+    # ---- postprocess + PSNR fixture (inference.py:54-61; evaluation.py:194-205) -----------
+    f1, f2 = O.make_frames(12, 2, 64, 64)
+    with torch.no_grad():
+        out = model(f1[:1], f2[:1])
+    u8 = O.postprocess_tensor(out)
+    gt = O.postprocess_tensor(0.5 * (f1[:1] + f2[:1]))
+    np.savez_compressed(os.path.join(GOLD, "post_b1_64x64.npz"),
+                        out=out.numpy(), u8=u8, gt_u8=gt, psnr=np.float64(O.psnr_u8(gt, u8)))
+    print("done; files:", sorted(os.listdir(GOLD)))
+
+
+if __name__ == "__main__":
+    main()
