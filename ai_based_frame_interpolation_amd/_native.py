@@ -1,0 +1,177 @@
+"""ctypes binding of libfiunet_hip.so (C ABI declared in include/fiunet.h).
+
+PyTorch is only the plumbing here: it owns device memory (caching allocator) and the HIP
+stream; every arithmetic op of the forward runs in the hand-written HIP kernels behind this
+ABI.  There is NO fallback: if the shared library is missing or a call fails, a RuntimeError
+is raised (the reference raises RuntimeError from torch for bad shapes too).
+
+`import torch` must happen before the library is loaded so that the process-wide HIP runtime
+is the one PyTorch-ROCm ships (same SONAME libamdhip64.so.7); the library then shares
+torch's device context, allocator pointers and streams.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+import subprocess
+
+import torch  # noqa: F401  (must precede CDLL: see module docstring)
+
+_PKG = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_PKG, "libfiunet_hip.so")
+CSRC = os.path.join(_PKG, "csrc")
+
+FP32, BF16 = 0, 1
+OPT_UNFUSED, OPT_KEEP_ALL = 1, 2
+
+#: every symbol include/fiunet.h declares (tests/test_abi.py checks the header against this)
+SYMBOLS = (
+    "fiunet_abi_version", "fiunet_last_error_string", "fiunet_create", "fiunet_destroy",
+    "fiunet_set_options", "fiunet_load_weights", "fiunet_workspace_bytes", "fiunet_forward",
+    "fiunet_workspace_bytes_u8", "fiunet_forward_u8", "fiunet_preprocess_u8",
+    "fiunet_postprocess_u8", "fiunet_debug_read_activation",
+)
+
+_lib = None
+
+
+def build(force: bool = False) -> str:
+    """Compile the HIP extension in-tree for gfx950 (hipcc cross-compiles without a GPU)."""
+    if force and os.path.exists(LIB_PATH):
+        os.remove(LIB_PATH)
+    res = subprocess.run(["make", "-C", CSRC], capture_output=True, text=True)
+    if res.returncode != 0 or not os.path.exists(LIB_PATH):
+        raise RuntimeError("building libfiunet_hip.so failed:\n" + res.stdout + res.stderr)
+    return LIB_PATH
+
+
+def lib() -> ctypes.CDLL:
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            f"{LIB_PATH} is missing: the MI355X HIP extension has not been built "
+            "(run `python -c 'import __graft_entry__ as g; g.build()'` or `make -C "
+            f"{CSRC}`).  There is no CPU fallback for this path.")
+    L = ctypes.CDLL(LIB_PATH)
+    vp, ci, sz = ctypes.c_void_p, ctypes.c_int, ctypes.c_size_t
+    L.fiunet_abi_version.restype = ci
+    L.fiunet_last_error_string.restype = ctypes.c_char_p
+    L.fiunet_create.argtypes = [ctypes.POINTER(vp), ci, ci, ci]
+    L.fiunet_destroy.argtypes = [vp]
+    L.fiunet_set_options.argtypes = [vp, ctypes.c_uint]
+    L.fiunet_load_weights.argtypes = [vp, ci, ctypes.POINTER(ctypes.c_char_p),
+                                      ctypes.POINTER(vp), ctypes.POINTER(ctypes.c_int64)]
+    L.fiunet_workspace_bytes.argtypes = [vp, ci, ci, ci, ci]
+    L.fiunet_workspace_bytes.restype = sz
+    L.fiunet_workspace_bytes_u8.argtypes = [vp, ci, ci, ci, ci]
+    L.fiunet_workspace_bytes_u8.restype = sz
+    L.fiunet_forward.argtypes = [vp, vp, vp, vp, ci, ci, ci, ci, vp, sz, vp]
+    L.fiunet_forward_u8.argtypes = [vp, vp, vp, vp, ci, ci, ci, ci, vp, sz, vp]
+    L.fiunet_preprocess_u8.argtypes = [vp, vp, sz, vp]
+    L.fiunet_postprocess_u8.argtypes = [vp, vp, sz, vp]
+    L.fiunet_debug_read_activation.argtypes = [vp, vp, ci, ci, ci, ci, ci, vp,
+                                               ctypes.POINTER(ci), vp]
+    for name in SYMBOLS:
+        getattr(L, name)  # AttributeError here = the .so does not export what the header declares
+    _lib = L
+    return L
+
+
+def check(rc: int, what: str) -> None:
+    if rc != 0:
+        msg = lib().fiunet_last_error_string()
+        raise RuntimeError(f"{what} failed (status {rc}): {msg.decode() if msg else '?'}")
+
+
+class Context:
+    """Owns one fiunet_ctx (device-resident prepared weights) on one GPU."""
+
+    def __init__(self, device_index: int, frame_channels: int = 1, bilinear: bool = True):
+        self._h = ctypes.c_void_p()
+        check(lib().fiunet_create(ctypes.byref(self._h), device_index, frame_channels,
+                                  1 if bilinear else 0), "fiunet_create")
+        self.device_index = device_index
+        self.frame_channels = frame_channels
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h:
+            lib().fiunet_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_options(self, flags: int):
+        check(lib().fiunet_set_options(self._h, flags), "fiunet_set_options")
+
+    def load_state_dict(self, sd) -> None:
+        names, ptrs, numels, keep = [], [], [], []
+        for k, v in sd.items():
+            if k.endswith("num_batches_tracked"):
+                continue
+            t = v.detach().to(device="cpu", dtype=torch.float32).contiguous()
+            keep.append(t)
+            names.append(k.encode())
+            ptrs.append(t.data_ptr())
+            numels.append(t.numel())
+        n = len(names)
+        check(lib().fiunet_load_weights(
+            self._h, n, (ctypes.c_char_p * n)(*names), (ctypes.c_void_p * n)(*ptrs),
+            (ctypes.c_int64 * n)(*numels)), "fiunet_load_weights")
+
+    def workspace_bytes(self, b, h, w, precision, u8=False) -> int:
+        fn = lib().fiunet_workspace_bytes_u8 if u8 else lib().fiunet_workspace_bytes
+        n = fn(self._h, b, h, w, precision)
+        if n == 0:
+            if h < 16 or w < 16:
+                raise RuntimeError(f"input {h}x{w} is too small for four 2x2 max-pools (need >= 16)")
+            check(1, "fiunet_workspace_bytes")
+        return n
+
+    def forward(self, f1, f2, out, precision, workspace, stream=None):
+        b, _, h, w = f1.shape
+        s = torch.cuda.current_stream(f1.device).cuda_stream if stream is None else stream
+        check(lib().fiunet_forward(self._h, f1.data_ptr(), f2.data_ptr(), out.data_ptr(), b, h, w,
+                                   precision, workspace.data_ptr(), workspace.numel(), s),
+              "fiunet_forward")
+
+    def forward_u8(self, f1, f2, out, precision, workspace, stream=None):
+        b, _, h, w = f1.shape
+        s = torch.cuda.current_stream(f1.device).cuda_stream if stream is None else stream
+        check(lib().fiunet_forward_u8(self._h, f1.data_ptr(), f2.data_ptr(), out.data_ptr(), b, h,
+                                      w, precision, workspace.data_ptr(), workspace.numel(), s),
+              "fiunet_forward_u8")
+
+    def read_activation(self, workspace, b, h, w, precision, tap):
+        dims = (ctypes.c_int * 3)()
+        from . import unet as _u  # local import: layer table lives with the module mirror
+        c, lv = _u.TAP_CHANNELS[tap], _u.TAP_LEVEL[tap]
+        hh, ww = h >> lv, w >> lv
+        dst = torch.empty((b, c, hh, ww), dtype=torch.float32, device=workspace.device)
+        s = torch.cuda.current_stream(workspace.device).cuda_stream
+        check(lib().fiunet_debug_read_activation(self._h, workspace.data_ptr(), b, h, w, precision,
+                                                 tap, dst.data_ptr(), dims, s),
+              "fiunet_debug_read_activation")
+        assert tuple(dims) == (c, hh, ww), (tuple(dims), (c, hh, ww))
+        return dst
+
+
+def preprocess_u8(src_u8: "torch.Tensor") -> "torch.Tensor":
+    out = torch.empty(src_u8.shape, dtype=torch.float32, device=src_u8.device)
+    s = torch.cuda.current_stream(src_u8.device).cuda_stream
+    check(lib().fiunet_preprocess_u8(src_u8.data_ptr(), out.data_ptr(), src_u8.numel(), s),
+          "fiunet_preprocess_u8")
+    return out
+
+
+def postprocess_u8(src_f32: "torch.Tensor") -> "torch.Tensor":
+    out = torch.empty(src_f32.shape, dtype=torch.uint8, device=src_f32.device)
+    s = torch.cuda.current_stream(src_f32.device).cuda_stream
+    check(lib().fiunet_postprocess_u8(src_f32.data_ptr(), out.data_ptr(), src_f32.numel(), s),
+          "fiunet_postprocess_u8")
+    return out

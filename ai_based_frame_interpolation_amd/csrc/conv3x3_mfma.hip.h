@@ -1,0 +1,359 @@
+// conv3x3_mfma.hip.h -- fused 3x3 conv (pad 1, no bias) + per-channel scale/shift (eval BatchNorm)
+// + ReLU as an implicit GEMM on the CDNA4 matrix cores, NHWC, for gfx950 only.
+//
+// Replaces the aten conv2d + batch_norm + relu triple behind DoubleConv
+// (/root/reference/model/unet.py:11-18) and, through the SRC_* gather modes, also the MaxPool2d
+// of Down (unet.py:28) and the Upsample + F.pad + torch.cat of Up (unet.py:46-54), which are
+// folded into the input-tile gather instead of being materialised in HBM.
+//
+// Mapping onto the hardware (one workgroup = 4 waves = 256 threads, 2 workgroups per CU):
+//   * GEMM view: D[cout][pixel] += W[cout][k] * X[k][pixel], k = (channel plane, ky, kx).
+//     MFMA A operand = weights (16 couts x 8k per lane-row), B operand = pixels.  With that
+//     orientation a lane of the 16x16 accumulator holds 4 consecutive couts of one pixel, so the
+//     NHWC epilogue stores 8 (bf16) / 16 (fp32) contiguous bytes per lane.
+//   * A "plane" is 64 bytes of channels per pixel (32 bf16 or 16 fp32).  The input tile
+//     (TH+2)x(TW+2) pixels of one plane is staged in LDS ONCE and reused by all 9 taps -- the
+//     shifted windows are just different LDS addresses (base + immediate offset).
+//   * Weights for (plane, ky, kx=0..2) are staged per step: 3*BN rows of 64 B.
+//   * Both LDS images are [row][64 B] with the 16-B chunk index XOR-ed by ((row>>2)&1)<<1, which
+//     makes every ds_read_b128 of 16 consecutive rows x 4 chunks conflict-free for any row
+//     alignment (the 16-lane groups of ds_read_b128 are listed in MI355X_MICROARCH.md, LDS).
+//     The in-tile row pitch is padded to a multiple of 8 pixels so the swizzle term of a lane
+//     does not depend on the tile row.
+//   * Each wave owns 64 couts x 128 pixels = 4 x 8 accumulator tiles (128 VGPRs).
+//   * bf16: v_mfma_f32_16x16x32_bf16 (one per A/B chunk pair); fp32: 4 x v_mfma_f32_16x16x4_f32
+//     per chunk pair (exact fp32 FMA chain) -- same kernel body, same LDS images.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace fiunet {
+
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+
+enum SrcMode { SRC_DIRECT = 0, SRC_POOL = 1, SRC_CONCAT_UP = 2 };
+
+struct ConvArgs {
+    const void* src0;    // DIRECT/CONCAT_UP: [B][H][W][C0]; POOL: [B][s0H][s0W][C0] (pre-pool)
+    const void* src1;    // CONCAT_UP: low-res [B][lowH][lowW][C1], bilinearly upsampled on the fly
+    const void* wgt;     // [Cin/PL][9][Cout][PL]  (plane-major, then tap, cout, channel-in-plane)
+    const float* scale;  // [Cout]  gamma / sqrt(var + eps)
+    const float* shift;  // [Cout]  beta - mean * scale
+    void* dst;           // [B][H][W][Cout] or nullptr (fused head only)
+    int B, H, W;         // conv input == output spatial size
+    int C0, C1, Cout;
+    int s0H, s0W;        // POOL: spatial size of src0
+    int lowH, lowW;      // CONCAT_UP: spatial size of src1
+    int padT, padL;      // CONCAT_UP: F.pad top/left (unet.py:52-53)
+    float sy, sx;        // CONCAT_UP: (low-1)/(2*low-1), align_corners=True scale
+    int tilesX, tilesY, nct;
+    int relu;
+    const float* head_w; // fused 1x1 head: [head_nc][64]
+    const float* head_b; // [head_nc]
+    float* head_out;     // fp32 NCHW [B][head_nc][H][W]
+    int head_nc;
+};
+
+template <typename T> struct Elem;
+template <> struct Elem<float> {
+    static constexpr int PL = 16;  // channels per 64-B plane
+    static constexpr int NE = 4;   // elements per 16-B chunk
+};
+template <> struct Elem<__bf16> {
+    static constexpr int PL = 32;
+    static constexpr int NE = 8;
+};
+
+// ---- 16-byte chunk helpers -------------------------------------------------------------------
+template <typename T> __device__ __forceinline__ void chunk_unpack(const uint4& c, float* f);
+template <> __device__ __forceinline__ void chunk_unpack<float>(const uint4& c, float* f)
+{
+    f[0] = __uint_as_float(c.x); f[1] = __uint_as_float(c.y);
+    f[2] = __uint_as_float(c.z); f[3] = __uint_as_float(c.w);
+}
+template <> __device__ __forceinline__ void chunk_unpack<__bf16>(const uint4& c, float* f)
+{
+    f[0] = __uint_as_float(c.x << 16); f[1] = __uint_as_float(c.x & 0xffff0000u);
+    f[2] = __uint_as_float(c.y << 16); f[3] = __uint_as_float(c.y & 0xffff0000u);
+    f[4] = __uint_as_float(c.z << 16); f[5] = __uint_as_float(c.z & 0xffff0000u);
+    f[6] = __uint_as_float(c.w << 16); f[7] = __uint_as_float(c.w & 0xffff0000u);
+}
+__device__ __forceinline__ unsigned pack_bf16x2(float lo, float hi)
+{
+    typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+    bf16x2 v = {(__bf16)lo, (__bf16)hi};  // v_cvt_pk_bf16_f32, round-to-nearest-even
+    return __builtin_bit_cast(unsigned, v);
+}
+template <typename T> __device__ __forceinline__ uint4 chunk_pack(const float* f);
+template <> __device__ __forceinline__ uint4 chunk_pack<float>(const float* f)
+{
+    return make_uint4(__float_as_uint(f[0]), __float_as_uint(f[1]), __float_as_uint(f[2]),
+                      __float_as_uint(f[3]));
+}
+template <> __device__ __forceinline__ uint4 chunk_pack<__bf16>(const float* f)
+{
+    return make_uint4(pack_bf16x2(f[0], f[1]), pack_bf16x2(f[2], f[3]), pack_bf16x2(f[4], f[5]),
+                      pack_bf16x2(f[6], f[7]));
+}
+
+template <typename T>
+__device__ __forceinline__ uint4 chunk_max4(const uint4& a, const uint4& b, const uint4& c,
+                                            const uint4& d)
+{
+    constexpr int NE = Elem<T>::NE;
+    float fa[NE], fb[NE], fc[NE], fd[NE], r[NE];
+    chunk_unpack<T>(a, fa); chunk_unpack<T>(b, fb); chunk_unpack<T>(c, fc); chunk_unpack<T>(d, fd);
+#pragma unroll
+    for (int i = 0; i < NE; ++i) r[i] = fmaxf(fmaxf(fa[i], fb[i]), fmaxf(fc[i], fd[i]));
+    return chunk_pack<T>(r);  // exact for bf16: the max is one of the (bf16) inputs
+}
+
+// hy*(hx*a + lx*b) + ly*(hx*c + lx*d): the association aten's upsample_bilinear2d uses.
+template <typename T>
+__device__ __forceinline__ uint4 chunk_bilerp(const uint4& a, const uint4& b, const uint4& c,
+                                              const uint4& d, float hx, float lx, float hy,
+                                              float ly)
+{
+    constexpr int NE = Elem<T>::NE;
+    float fa[NE], fb[NE], fc[NE], fd[NE], r[NE];
+    chunk_unpack<T>(a, fa); chunk_unpack<T>(b, fb); chunk_unpack<T>(c, fc); chunk_unpack<T>(d, fd);
+#pragma unroll
+    for (int i = 0; i < NE; ++i)
+        r[i] = hy * (hx * fa[i] + lx * fb[i]) + ly * (hx * fc[i] + lx * fd[i]);
+    return chunk_pack<T>(r);
+}
+
+__device__ __forceinline__ uint4 ldg16(const char* p) { return *reinterpret_cast<const uint4*>(p); }
+
+// One 16-byte chunk (plane `plane`, chunk `ch`) of conv-input pixel (b, y, x); zero outside.
+template <typename T, int MODE>
+__device__ __forceinline__ uint4 gather_chunk(const ConvArgs& a, int b, int y, int x, int plane,
+                                              int ch)
+{
+    constexpr int PL = Elem<T>::PL;
+    uint4 z = make_uint4(0u, 0u, 0u, 0u);
+    if (y < 0 || y >= a.H || x < 0 || x >= a.W) return z;
+    const int p0 = a.C0 / PL;
+    if (MODE == SRC_POOL) {
+        const size_t rowb = (size_t)a.s0W * a.C0 * sizeof(T);
+        const char* p = (const char*)a.src0 +
+                        (((size_t)b * a.s0H + 2 * y) * a.s0W + 2 * x) * a.C0 * sizeof(T) +
+                        plane * 64 + ch * 16;
+        const size_t pxb = (size_t)a.C0 * sizeof(T);
+        return chunk_max4<T>(ldg16(p), ldg16(p + pxb), ldg16(p + rowb), ldg16(p + rowb + pxb));
+    }
+    if (MODE == SRC_DIRECT || plane < p0) {
+        const char* p = (const char*)a.src0 +
+                        (((size_t)b * a.H + y) * a.W + x) * a.C0 * sizeof(T) + plane * 64 + ch * 16;
+        return ldg16(p);
+    }
+    // CONCAT_UP, upsampled half: channels C0.. come from bilinear x2 of src1, zero-padded.
+    const int yu = y - a.padT, xu = x - a.padL;
+    if (yu < 0 || yu >= 2 * a.lowH || xu < 0 || xu >= 2 * a.lowW) return z;
+    const float fy = a.sy * (float)yu, fx = a.sx * (float)xu;
+    const int y0 = (int)fy, x0 = (int)fx;
+    const int y1 = y0 < a.lowH - 1 ? y0 + 1 : y0, x1 = x0 < a.lowW - 1 ? x0 + 1 : x0;
+    const float ly = fy - (float)y0, lx = fx - (float)x0;
+    const float hy = 1.0f - ly, hx = 1.0f - lx;
+    const char* base = (const char*)a.src1 + (size_t)b * a.lowH * a.lowW * a.C1 * sizeof(T) +
+                       (plane - p0) * 64 + ch * 16;
+    const size_t pxb = (size_t)a.C1 * sizeof(T);
+    const uint4 v00 = ldg16(base + ((size_t)y0 * a.lowW + x0) * pxb);
+    const uint4 v01 = ldg16(base + ((size_t)y0 * a.lowW + x1) * pxb);
+    const uint4 v10 = ldg16(base + ((size_t)y1 * a.lowW + x0) * pxb);
+    const uint4 v11 = ldg16(base + ((size_t)y1 * a.lowW + x1) * pxb);
+    return chunk_bilerp<T>(v00, v01, v10, v11, hx, lx, hy, ly);
+}
+
+__device__ __forceinline__ int swz(int row) { return ((row >> 2) & 1) << 1; }
+
+template <typename T>
+__device__ __forceinline__ void mma_chunk(f32x4& acc, const uint4& wa, const uint4& xb);
+template <>
+__device__ __forceinline__ void mma_chunk<__bf16>(f32x4& acc, const uint4& wa, const uint4& xb)
+{
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wa),
+                                                  __builtin_bit_cast(bf16x8, xb), acc, 0, 0, 0);
+}
+template <>
+__device__ __forceinline__ void mma_chunk<float>(f32x4& acc, const uint4& wa, const uint4& xb)
+{
+    // lane group g = lane>>4 holds channels 4g..4g+3 of the plane in both operands; MFMA i
+    // consumes element i of every group, i.e. k-slot g <-> channel 4g+i on both sides.
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(wa.x), __uint_as_float(xb.x), acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(wa.y), __uint_as_float(xb.y), acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(wa.z), __uint_as_float(xb.z), acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(wa.w), __uint_as_float(xb.w), acc, 0, 0, 0);
+}
+
+template <int BN, int TH, int TW> struct ConvTile {
+    static constexpr int TWP = ((TW + 2 + 7) / 8) * 8;  // in-tile row pitch, multiple of 8 pixels
+    static constexpr int THP = TH + 2;
+    static constexpr int IN_BYTES = THP * TWP * 64;
+    static constexpr int W_BYTES = 3 * BN * 64;
+    static constexpr int LDS_BYTES = IN_BYTES + W_BYTES;
+};
+
+template <typename T, int BN, int TH, int TW, int MODE, bool HEAD>
+__global__ __launch_bounds__(256, 2) void conv3x3_mfma_kernel(const ConvArgs a)
+{
+    using Tile = ConvTile<BN, TH, TW>;
+    constexpr int PL = Elem<T>::PL;
+    constexpr int TWP = Tile::TWP, THP = Tile::THP;
+    constexpr int WAVES_C = BN / 64, WAVES_P = 4 / WAVES_C;
+    constexpr int FR = TW / 16;       // 16-pixel fragments per tile row
+    constexpr int ROWS_W = 8 / FR;    // tile rows per wave
+    static_assert(TH == ROWS_W * WAVES_P, "wave tile must be 64 couts x 128 pixels");
+    static_assert(!HEAD || BN == 64, "fused head needs all 64 couts in one wave");
+
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* lds_in = smem;
+    char* lds_w = smem + Tile::IN_BYTES;
+
+    // XCD-aware, bijective block remap: blocks sharing an input tile (different cout tiles) and
+    // neighbouring tiles get consecutive logical ids on ONE XCD so the re-reads hit its L2.
+    int lid;
+    {
+        const int nblk = gridDim.x, bid = blockIdx.x;
+        const int q = nblk >> 3, r = nblk & 7, xcd = bid & 7;
+        lid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+    }
+    const int ct = lid % a.nct;
+    int t = lid / a.nct;
+    const int tx = t % a.tilesX; t /= a.tilesX;
+    const int ty = t % a.tilesY;
+    const int b = t / a.tilesY;
+    const int y0 = ty * TH, x0 = tx * TW;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int l15 = lane & 15, lc = lane >> 4;
+    const int wc = wave % WAVES_C, wp = wave / WAVES_C;
+
+    f32x4 acc[4][8];
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+#pragma unroll
+        for (int n = 0; n < 8; ++n) acc[m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    // per-lane LDS read offsets (everything else is an immediate)
+    const int a_off = (wc * 64 + l15) * 64 + ((lc ^ swz(l15)) << 4);
+    int b_off[3];
+#pragma unroll
+    for (int kx = 0; kx < 3; ++kx)
+        b_off[kx] = (wp * ROWS_W * TWP + kx + l15) * 64 + ((lc ^ swz(kx + l15)) << 4);
+
+    const int nplanes = (a.C0 + a.C1) / PL;
+    const char* wbase = (const char*)a.wgt + (size_t)ct * BN * 64;
+
+    for (int plane = 0; plane < nplanes; ++plane) {
+        for (int ky = 0; ky < 3; ++ky) {
+            __syncthreads();  // previous step's LDS reads are done
+            if (ky == 0) {
+                for (int i = tid; i < THP * (TW + 2) * 4; i += 256) {
+                    const int pix = i >> 2, ch = i & 3;
+                    const int py = pix / (TW + 2), px = pix - py * (TW + 2);
+                    const uint4 v = gather_chunk<T, MODE>(a, b, y0 - 1 + py, x0 - 1 + px, plane, ch);
+                    const int row = py * TWP + px;
+                    *reinterpret_cast<uint4*>(lds_in + row * 64 + ((ch ^ swz(row)) << 4)) = v;
+                }
+            }
+            {
+                const char* wsrc = wbase + ((size_t)(plane * 9 + ky * 3) * a.Cout) * 64;
+#pragma unroll
+                for (int i = tid; i < 3 * BN * 4; i += 256) {
+                    const int kx = i / (BN * 4), rem = i - kx * (BN * 4);
+                    const int row = rem >> 2, ch = rem & 3;
+                    const uint4 v = ldg16(wsrc + ((size_t)kx * a.Cout + row) * 64 + ch * 16);
+                    const int lrow = kx * BN + row;
+                    *reinterpret_cast<uint4*>(lds_w + lrow * 64 + ((ch ^ swz(lrow)) << 4)) = v;
+                }
+            }
+            __syncthreads();
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx) {
+                uint4 wa[4], xb[8];
+#pragma unroll
+                for (int m = 0; m < 4; ++m)
+                    wa[m] = *reinterpret_cast<const uint4*>(lds_w + a_off + (kx * BN + m * 16) * 64);
+#pragma unroll
+                for (int n = 0; n < 8; ++n)
+                    xb[n] = *reinterpret_cast<const uint4*>(
+                        lds_in + b_off[kx] + (((n / FR) + ky) * TWP + (n % FR) * 16) * 64);
+#pragma unroll
+                for (int m = 0; m < 4; ++m)
+#pragma unroll
+                    for (int n = 0; n < 8; ++n) mma_chunk<T>(acc[m][n], wa[m], xb[n]);
+            }
+        }
+    }
+
+    // ---- epilogue: y = relu(acc * scale + shift); lane holds couts cbase+m*16+lc*4+{0..3} ----
+    const int cbase = ct * BN + wc * 64 + lc * 4;
+    float4 sc[4], sh[4];
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+        sc[m] = *reinterpret_cast<const float4*>(a.scale + cbase + m * 16);
+        sh[m] = *reinterpret_cast<const float4*>(a.shift + cbase + m * 16);
+    }
+    float hw[3][4][4];
+    if (HEAD) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c)
+#pragma unroll
+            for (int m = 0; m < 4; ++m) {
+                const float4 v = c < a.head_nc
+                    ? *reinterpret_cast<const float4*>(a.head_w + c * 64 + lc * 4 + m * 16)
+                    : make_float4(0.f, 0.f, 0.f, 0.f);
+                hw[c][m][0] = v.x; hw[c][m][1] = v.y; hw[c][m][2] = v.z; hw[c][m][3] = v.w;
+            }
+    }
+#pragma unroll
+    for (int n = 0; n < 8; ++n) {
+        const int y = y0 + wp * ROWS_W + n / FR;
+        const int x = x0 + (n % FR) * 16 + l15;
+        const bool ok = (y < a.H) && (x < a.W);
+        const size_t pix = ((size_t)b * a.H + y) * a.W + x;
+        float hsum[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+            float v[4];
+            v[0] = acc[m][n][0] * sc[m].x + sh[m].x;
+            v[1] = acc[m][n][1] * sc[m].y + sh[m].y;
+            v[2] = acc[m][n][2] * sc[m].z + sh[m].z;
+            v[3] = acc[m][n][3] * sc[m].w + sh[m].w;
+            if (a.relu) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) v[j] = fmaxf(v[j], 0.f);
+            }
+            if (HEAD) {
+#pragma unroll
+                for (int c = 0; c < 3; ++c)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) hsum[c] = fmaf(v[j], hw[c][m][j], hsum[c]);
+            }
+            if (ok && a.dst) {
+                T* o = (T*)a.dst + pix * a.Cout + cbase + m * 16;
+                if constexpr (sizeof(T) == 4) {
+                    *reinterpret_cast<float4*>(o) = make_float4(v[0], v[1], v[2], v[3]);
+                } else {
+                    *reinterpret_cast<uint2*>(o) =
+                        make_uint2(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]));
+                }
+            }
+        }
+        if (HEAD) {
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                float s = hsum[c];
+                s += __shfl_xor(s, 16);
+                s += __shfl_xor(s, 32);
+                if (c < a.head_nc && ok && lc == 0)
+                    a.head_out[(((size_t)b * a.head_nc + c) * a.H + y) * a.W + x] = s + a.head_b[c];
+            }
+        }
+    }
+}
+
+}  // namespace fiunet

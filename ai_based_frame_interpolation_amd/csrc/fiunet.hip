@@ -1,0 +1,491 @@
+// fiunet.hip -- C ABI (include/fiunet.h) + host orchestration of the MI355X UNet forward.
+//
+// Replaces, for the hot path only, the Python surface of the reference:
+//   FrameInterpolationUNet.__init__/forward   /root/reference/model/unet.py:97-112
+//   UNet.__init__/forward (wiring)            /root/reference/model/unet.py:65-95
+//   load_state_dict + .to(device) + .eval()   /root/reference/model/inference.py:83-97
+//   pre/post-processing arithmetic            /root/reference/model/inference.py:31-35, :54-61
+// Device code: conv3x3_mfma.hip.h (MFMA implicit-GEMM conv) and pointwise.hip.h.
+// gfx950 only; no CPU fallback: every entry point either launches HIP kernels or returns an error.
+#include "../../include/fiunet.h"
+#include "pointwise.hip.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+using namespace fiunet;
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(int code, const std::string& msg)
+{
+    g_err = msg;
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                     \
+    do {                                                                                  \
+        hipError_t e_ = (expr);                                                           \
+        if (e_ != hipSuccess)                                                             \
+            return fail(FIUNET_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_)); \
+    } while (0)
+
+constexpr int NCONV = 18;
+// conv index = 2*block + {0,1}; blocks: inc, down1..4, up1..4 (state-dict order)
+const char* const kBlockPrefix[9] = {
+    "unet.inc", "unet.down1.maxpool_conv.1", "unet.down2.maxpool_conv.1",
+    "unet.down3.maxpool_conv.1", "unet.down4.maxpool_conv.1", "unet.up1.conv", "unet.up2.conv",
+    "unet.up3.conv", "unet.up4.conv"};
+const int kCout[NCONV] = {64, 64, 128, 128, 256, 256, 512, 512, 512, 512, 512, 256, 256, 128, 128, 64, 64, 64};
+const int kLevel[NCONV] = {0, 0, 1, 1, 2, 2, 3, 3, 4, 4, 3, 3, 2, 2, 1, 1, 0, 0};
+// gather mode and sources (activation indices) of each conv; conv 0 is the fp32 stem kernel
+const int kMode[NCONV] = {-1, SRC_DIRECT, SRC_POOL, SRC_DIRECT, SRC_POOL, SRC_DIRECT, SRC_POOL,
+                          SRC_DIRECT, SRC_POOL, SRC_DIRECT, SRC_CONCAT_UP, SRC_DIRECT,
+                          SRC_CONCAT_UP, SRC_DIRECT, SRC_CONCAT_UP, SRC_DIRECT, SRC_CONCAT_UP,
+                          SRC_DIRECT};
+const int kSrc0[NCONV] = {-1, 0, 1, 2, 3, 4, 5, 6, 7, 8, 7, 10, 5, 12, 3, 14, 1, 16};
+const int kSrc1[NCONV] = {-1, -1, -1, -1, -1, -1, -1, -1, -1, -1, 9, -1, 11, -1, 13, -1, 15, -1};
+
+struct ConvWeights {
+    int cin = 0, cout = 0;
+    void* w_f32 = nullptr;   // packed [cin/16][9][cout][16] fp32   (conv 0: [9][cin][64])
+    void* w_bf16 = nullptr;  // packed [cin/32][9][cout][32] bf16
+    float* scale = nullptr;
+    float* shift = nullptr;
+};
+
+uint16_t f32_to_bf16_rne(float f)
+{
+    uint32_t u;
+    std::memcpy(&u, &f, 4);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x40);  // NaN stays NaN
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (uint16_t)(u >> 16);
+}
+
+inline size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
+
+struct Plan {
+    int hs[5], ws[5];
+    size_t act_off[NCONV];
+    size_t scratch_off;
+    size_t total;
+};
+
+bool make_plan(int B, int H, int W, int precision, Plan& p)
+{
+    if (B < 1 || H < 16 || W < 16) return false;
+    const size_t es = precision == FIUNET_BF16 ? 2 : 4;
+    p.hs[0] = H; p.ws[0] = W;
+    for (int k = 1; k < 5; ++k) { p.hs[k] = p.hs[k - 1] / 2; p.ws[k] = p.ws[k - 1] / 2; }
+    size_t off = 0;
+    for (int i = 0; i < NCONV; ++i) {
+        p.act_off[i] = off;
+        off += align256((size_t)B * p.hs[kLevel[i]] * p.ws[kLevel[i]] * kCout[i] * es);
+    }
+    p.scratch_off = off;  // ablation path: pooled tensor / concat tensor (<= 128 ch at level 0)
+    off += align256((size_t)B * H * W * 128 * es);
+    p.total = off;
+    return true;
+}
+
+}  // namespace
+
+struct fiunet_ctx {
+    int device = 0;
+    int cf = 1;  // channels per frame
+    unsigned flags = 0;
+    bool loaded = false;
+    ConvWeights conv[NCONV];
+    float* head_w = nullptr;  // [cf][64]
+    float* head_b = nullptr;  // [cf]
+    std::vector<void*> owned;
+};
+
+namespace {
+
+int dev_upload(fiunet_ctx* ctx, const void* host, size_t bytes, void** out)
+{
+    void* d = nullptr;
+    HIP_TRY(hipMalloc(&d, bytes));
+    ctx->owned.push_back(d);
+    HIP_TRY(hipMemcpy(d, host, bytes, hipMemcpyHostToDevice));
+    *out = d;
+    return FIUNET_OK;
+}
+
+void free_weights(fiunet_ctx* ctx)
+{
+    for (void* p : ctx->owned) (void)hipFree(p);
+    ctx->owned.clear();
+    ctx->loaded = false;
+}
+
+template <typename T, int BN, int TH, int TW, int MODE, bool HEAD>
+int launch_conv_cfg(ConvArgs a, hipStream_t s)
+{
+    using Tile = ConvTile<BN, TH, TW>;
+    a.tilesX = (a.W + TW - 1) / TW;
+    a.tilesY = (a.H + TH - 1) / TH;
+    a.nct = a.Cout / BN;
+    const long long nblk = (long long)a.B * a.tilesX * a.tilesY * a.nct;
+    if (nblk <= 0 || nblk > 0x7fffffffLL) return fail(FIUNET_ERR_INVALID_ARG, "conv grid too large");
+    hipLaunchKernelGGL((conv3x3_mfma_kernel<T, BN, TH, TW, MODE, HEAD>), dim3((unsigned)nblk),
+                       dim3(256), Tile::LDS_BYTES, s, a);
+    HIP_TRY(hipGetLastError());
+    return FIUNET_OK;
+}
+
+inline long long padded_area(int H, int W, int TH, int TW)
+{
+    return (long long)((H + TH - 1) / TH) * TH * ((W + TW - 1) / TW) * TW;
+}
+
+template <typename T, int MODE>
+int launch_conv_mode(const ConvArgs& a, bool head, hipStream_t s)
+{
+    if (a.Cout == 64) {
+        const bool wide = padded_area(a.H, a.W, 16, 32) <= padded_area(a.H, a.W, 32, 16);
+        if constexpr (MODE == SRC_DIRECT) {
+            if (head)
+                return wide ? launch_conv_cfg<T, 64, 16, 32, MODE, true>(a, s)
+                            : launch_conv_cfg<T, 64, 32, 16, MODE, true>(a, s);
+        }
+        if constexpr (MODE != SRC_POOL)
+            return wide ? launch_conv_cfg<T, 64, 16, 32, MODE, false>(a, s)
+                        : launch_conv_cfg<T, 64, 32, 16, MODE, false>(a, s);
+        return fail(FIUNET_ERR_INVALID_ARG, "no pooled conv variant with 64 couts");
+    }
+    if (a.Cout % 128 != 0) return fail(FIUNET_ERR_INVALID_ARG, "Cout must be 64 or k*128");
+    const bool wide = padded_area(a.H, a.W, 8, 32) <= padded_area(a.H, a.W, 16, 16);
+    return wide ? launch_conv_cfg<T, 128, 8, 32, MODE, false>(a, s)
+                : launch_conv_cfg<T, 128, 16, 16, MODE, false>(a, s);
+}
+
+template <typename T> int launch_conv(const ConvArgs& a, int mode, bool head, hipStream_t s)
+{
+    constexpr int PL = Elem<T>::PL;
+    if (a.C0 % PL || a.C1 % PL) return fail(FIUNET_ERR_INVALID_ARG, "channels not a plane multiple");
+    switch (mode) {
+    case SRC_DIRECT: return launch_conv_mode<T, SRC_DIRECT>(a, head, s);
+    case SRC_POOL: return launch_conv_mode<T, SRC_POOL>(a, head, s);
+    case SRC_CONCAT_UP: return launch_conv_mode<T, SRC_CONCAT_UP>(a, head, s);
+    }
+    return fail(FIUNET_ERR_INVALID_ARG, "bad gather mode");
+}
+
+inline unsigned grid_for(size_t n) { return (unsigned)std::min<size_t>((n + 255) / 256, 256 * 32); }
+
+template <typename T>
+int forward_impl(fiunet_ctx* ctx, const float* f1, const float* f2, float* out, int B, int H,
+                 int W, char* ws, const Plan& p, hipStream_t s)
+{
+    const bool bf16 = sizeof(T) == 2;
+    const bool unfused = ctx->flags & FIUNET_OPT_UNFUSED;
+    auto act = [&](int i) { return (T*)(ws + p.act_off[i]); };
+    T* scratch = (T*)(ws + p.scratch_off);
+
+    // conv 0: fp32 stem (unet.py:72, first conv of inc)
+    {
+        const ConvWeights& cw = ctx->conv[0];
+        dim3 grid((W + 255) / 256, H, B);
+        if (ctx->cf == 1)
+            hipLaunchKernelGGL((conv3x3_first_kernel<T, 1>), grid, dim3(256), 0, s, f1, f2,
+                               (const float*)cw.w_f32, cw.scale, cw.shift, act(0), B, H, W);
+        else
+            hipLaunchKernelGGL((conv3x3_first_kernel<T, 3>), grid, dim3(256), 0, s, f1, f2,
+                               (const float*)cw.w_f32, cw.scale, cw.shift, act(0), B, H, W);
+        HIP_TRY(hipGetLastError());
+    }
+    for (int i = 1; i < NCONV; ++i) {
+        const ConvWeights& cw = ctx->conv[i];
+        const int lv = kLevel[i];
+        ConvArgs a;
+        std::memset(&a, 0, sizeof(a));
+        a.B = B; a.H = p.hs[lv]; a.W = p.ws[lv];
+        a.Cout = cw.cout;
+        a.wgt = bf16 ? cw.w_bf16 : cw.w_f32;
+        a.scale = cw.scale; a.shift = cw.shift;
+        a.relu = 1;
+        a.dst = act(i);
+        int mode = kMode[i];
+        a.src0 = act(kSrc0[i]);
+        a.C0 = kCout[kSrc0[i]];
+        if (mode == SRC_POOL) {
+            a.s0H = p.hs[lv - 1]; a.s0W = p.ws[lv - 1];
+        } else if (mode == SRC_CONCAT_UP) {
+            a.src1 = act(kSrc1[i]);
+            a.C1 = kCout[kSrc1[i]];
+            a.lowH = p.hs[lv + 1]; a.lowW = p.ws[lv + 1];
+            const int dy = a.H - 2 * a.lowH, dx = a.W - 2 * a.lowW;  // unet.py:49-53
+            a.padT = dy / 2; a.padL = dx / 2;
+            // aten area_pixel_compute_scale, align_corners=True: (in - 1) / (out - 1) in fp32
+            a.sy = 2 * a.lowH > 1 ? (float)(a.lowH - 1) / (float)(2 * a.lowH - 1) : 0.f;
+            a.sx = 2 * a.lowW > 1 ? (float)(a.lowW - 1) / (float)(2 * a.lowW - 1) : 0.f;
+        }
+        if (a.C0 + a.C1 != cw.cin) return fail(FIUNET_ERR_INVALID_ARG, "internal: channel plan mismatch");
+        if (unfused && mode == SRC_POOL) {
+            const size_t n = (size_t)B * a.H * a.W * (a.C0 * sizeof(T) / 16);
+            hipLaunchKernelGGL((maxpool2_kernel<T>), dim3(grid_for(n)), dim3(256), 0, s,
+                               (const T*)a.src0, scratch, B, a.s0H, a.s0W, a.C0);
+            HIP_TRY(hipGetLastError());
+            a.src0 = scratch; mode = SRC_DIRECT;
+        } else if (unfused && mode == SRC_CONCAT_UP) {
+            const size_t n = (size_t)B * a.H * a.W * ((a.C0 + a.C1) * sizeof(T) / 16);
+            hipLaunchKernelGGL((upcat_kernel<T>), dim3(grid_for(n)), dim3(256), 0, s, a, scratch);
+            HIP_TRY(hipGetLastError());
+            a.src0 = scratch; a.C0 = a.C0 + a.C1; a.C1 = 0; a.src1 = nullptr; mode = SRC_DIRECT;
+        }
+        bool head = false;
+        if (i == NCONV - 1 && !unfused) {  // fuse OutConv (unet.py:60) into the last epilogue
+            head = true;
+            a.head_w = ctx->head_w; a.head_b = ctx->head_b; a.head_out = out; a.head_nc = ctx->cf;
+            if (!(ctx->flags & FIUNET_OPT_KEEP_ALL)) a.dst = nullptr;
+        }
+        const int rc = launch_conv<T>(a, mode, head, s);
+        if (rc != FIUNET_OK) return rc;
+    }
+    if (unfused) {
+        const size_t n = (size_t)B * H * W;
+        hipLaunchKernelGGL((head1x1_kernel<T>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s,
+                           (const T*)act(NCONV - 1), ctx->head_w, ctx->head_b, out, B, H, W, ctx->cf);
+        HIP_TRY(hipGetLastError());
+    }
+    return FIUNET_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int fiunet_abi_version(void) { return FIUNET_ABI_VERSION; }
+
+const char* fiunet_last_error_string(void) { return g_err.c_str(); }
+
+int fiunet_create(fiunet_ctx** out_ctx, int device_id, int frame_channels, int bilinear)
+{
+    if (!out_ctx) return fail(FIUNET_ERR_INVALID_ARG, "out_ctx is NULL");
+    *out_ctx = nullptr;
+    if (frame_channels != 1 && frame_channels != 3)
+        return fail(FIUNET_ERR_INVALID_ARG, "frame_channels must be 1 (gray) or 3 (RGB)");
+    if (!bilinear)
+        return fail(FIUNET_ERR_UNSUPPORTED,
+                    "bilinear=False (ConvTranspose2d decoder) is not built; every reference caller "
+                    "constructs bilinear=True");
+    int ndev = 0;
+    HIP_TRY(hipGetDeviceCount(&ndev));
+    if (device_id < 0 || device_id >= ndev) return fail(FIUNET_ERR_INVALID_ARG, "bad device_id");
+    fiunet_ctx* c = new (std::nothrow) fiunet_ctx();
+    if (!c) return fail(FIUNET_ERR_INVALID_ARG, "out of host memory");
+    c->device = device_id;
+    c->cf = frame_channels;
+    *out_ctx = c;
+    return FIUNET_OK;
+}
+
+int fiunet_destroy(fiunet_ctx* ctx)
+{
+    if (!ctx) return FIUNET_OK;
+    (void)hipSetDevice(ctx->device);
+    free_weights(ctx);
+    delete ctx;
+    return FIUNET_OK;
+}
+
+int fiunet_set_options(fiunet_ctx* ctx, unsigned flags)
+{
+    if (!ctx) return fail(FIUNET_ERR_INVALID_ARG, "ctx is NULL");
+    ctx->flags = flags;
+    return FIUNET_OK;
+}
+
+int fiunet_load_weights(fiunet_ctx* ctx, int n, const char* const* names,
+                        const float* const* host_ptrs, const int64_t* numels)
+{
+    if (!ctx || n < 0 || !names || !host_ptrs || !numels)
+        return fail(FIUNET_ERR_INVALID_ARG, "NULL argument");
+    HIP_TRY(hipSetDevice(ctx->device));
+    std::map<std::string, std::pair<const float*, int64_t>> tab;
+    for (int i = 0; i < n; ++i)
+        if (names[i] && host_ptrs[i]) tab[names[i]] = {host_ptrs[i], numels[i]};
+    auto get = [&](const std::string& k, int64_t want, const float** out) -> int {
+        auto it = tab.find(k);
+        if (it == tab.end()) return fail(FIUNET_ERR_MISSING_WEIGHT, "missing state-dict key " + k);
+        if (it->second.second != want)
+            return fail(FIUNET_ERR_MISSING_WEIGHT, "size mismatch for " + k + ": got " +
+                            std::to_string(it->second.second) + ", want " + std::to_string(want));
+        *out = it->second.first;
+        return FIUNET_OK;
+    };
+    free_weights(ctx);
+    const int cin0 = 2 * ctx->cf;
+    for (int i = 0; i < NCONV; ++i) {
+        const int blk = i / 2, second = i % 2;
+        const std::string pre = std::string(kBlockPrefix[blk]) + ".double_conv.";
+        const std::string wk = pre + (second ? "3" : "0") + ".weight";
+        const std::string bn = pre + (second ? "4" : "1");
+        const int cout = kCout[i];
+        int cin;
+        if (i == 0) cin = cin0;
+        else if (kMode[i] == SRC_CONCAT_UP) cin = kCout[kSrc0[i]] + kCout[kSrc1[i]];
+        else cin = kCout[kSrc0[i]];
+        const float *w, *g, *be, *mu, *var;
+        int rc;
+        if ((rc = get(wk, (int64_t)cout * cin * 9, &w))) return rc;
+        if ((rc = get(bn + ".weight", cout, &g))) return rc;
+        if ((rc = get(bn + ".bias", cout, &be))) return rc;
+        if ((rc = get(bn + ".running_mean", cout, &mu))) return rc;
+        if ((rc = get(bn + ".running_var", cout, &var))) return rc;
+        ConvWeights& cw = ctx->conv[i];
+        cw.cin = cin; cw.cout = cout;
+        // eval-mode BatchNorm2d (eps = 1e-5, unet.py:13,16) folded to y = x*scale + shift
+        std::vector<float> sc(cout), sh(cout);
+        for (int c = 0; c < cout; ++c) {
+            const float inv = 1.0f / std::sqrt(var[c] + 1e-5f);
+            sc[c] = g[c] * inv;
+            sh[c] = be[c] - mu[c] * sc[c];
+        }
+        if ((rc = dev_upload(ctx, sc.data(), cout * 4, (void**)&cw.scale))) return rc;
+        if ((rc = dev_upload(ctx, sh.data(), cout * 4, (void**)&cw.shift))) return rc;
+        if (i == 0) {  // stem: [tap][cin][64] fp32
+            std::vector<float> pk((size_t)9 * cin * 64);
+            for (int co = 0; co < 64; ++co)
+                for (int ci = 0; ci < cin; ++ci)
+                    for (int t = 0; t < 9; ++t)
+                        pk[((size_t)t * cin + ci) * 64 + co] = w[((size_t)co * cin + ci) * 9 + t];
+            if ((rc = dev_upload(ctx, pk.data(), pk.size() * 4, &cw.w_f32))) return rc;
+            continue;
+        }
+        const size_t nel = (size_t)cout * cin * 9;
+        std::vector<float> p32(nel);
+        std::vector<uint16_t> p16(nel);
+        for (int co = 0; co < cout; ++co)
+            for (int ci = 0; ci < cin; ++ci)
+                for (int t = 0; t < 9; ++t) {
+                    const float v = w[((size_t)co * cin + ci) * 9 + t];
+                    p32[(((size_t)(ci / 16) * 9 + t) * cout + co) * 16 + (ci % 16)] = v;
+                    p16[(((size_t)(ci / 32) * 9 + t) * cout + co) * 32 + (ci % 32)] = f32_to_bf16_rne(v);
+                }
+        if ((rc = dev_upload(ctx, p32.data(), nel * 4, &cw.w_f32))) return rc;
+        if ((rc = dev_upload(ctx, p16.data(), nel * 2, &cw.w_bf16))) return rc;
+    }
+    {
+        const float *w, *bi;
+        int rc;
+        if ((rc = get("unet.outc.conv.weight", (int64_t)ctx->cf * 64, &w))) return rc;
+        if ((rc = get("unet.outc.conv.bias", ctx->cf, &bi))) return rc;
+        if ((rc = dev_upload(ctx, w, (size_t)ctx->cf * 64 * 4, (void**)&ctx->head_w))) return rc;
+        if ((rc = dev_upload(ctx, bi, (size_t)ctx->cf * 4, (void**)&ctx->head_b))) return rc;
+    }
+    ctx->loaded = true;
+    return FIUNET_OK;
+}
+
+size_t fiunet_workspace_bytes(const fiunet_ctx* ctx, int B, int H, int W, int precision)
+{
+    Plan p;
+    if (!ctx || (precision != FIUNET_FP32 && precision != FIUNET_BF16) || !make_plan(B, H, W, precision, p)) {
+        g_err = "fiunet_workspace_bytes: bad arguments";
+        return 0;
+    }
+    return p.total;
+}
+
+int fiunet_forward(fiunet_ctx* ctx, const float* frame1, const float* frame2, float* out, int B,
+                   int H, int W, int precision, void* workspace, size_t workspace_bytes,
+                   void* stream)
+{
+    if (!ctx || !frame1 || !frame2 || !out || !workspace)
+        return fail(FIUNET_ERR_INVALID_ARG, "NULL argument");
+    if (!ctx->loaded) return fail(FIUNET_ERR_NOT_LOADED, "fiunet_forward before fiunet_load_weights");
+    if (precision != FIUNET_FP32 && precision != FIUNET_BF16)
+        return fail(FIUNET_ERR_INVALID_ARG, "bad precision");
+    if (B < 1) return fail(FIUNET_ERR_INVALID_ARG, "B < 1");
+    if (H < 16 || W < 16)
+        return fail(FIUNET_ERR_BAD_SHAPE, "H and W must be >= 16 (four 2x2 max-pools)");
+    Plan p;
+    make_plan(B, H, W, precision, p);
+    if (workspace_bytes < p.total) return fail(FIUNET_ERR_WORKSPACE, "workspace too small");
+    if ((uintptr_t)workspace & 255) return fail(FIUNET_ERR_INVALID_ARG, "workspace not 256-B aligned");
+    HIP_TRY(hipSetDevice(ctx->device));
+    hipStream_t s = (hipStream_t)stream;
+    if (precision == FIUNET_BF16)
+        return forward_impl<__bf16>(ctx, frame1, frame2, out, B, H, W, (char*)workspace, p, s);
+    return forward_impl<float>(ctx, frame1, frame2, out, B, H, W, (char*)workspace, p, s);
+}
+
+size_t fiunet_workspace_bytes_u8(const fiunet_ctx* ctx, int B, int H, int W, int precision)
+{
+    const size_t base = fiunet_workspace_bytes(ctx, B, H, W, precision);
+    if (!base) return 0;
+    return base + 3 * align256((size_t)B * ctx->cf * H * W * 4);
+}
+
+int fiunet_forward_u8(fiunet_ctx* ctx, const uint8_t* frame1, const uint8_t* frame2, uint8_t* out,
+                      int B, int H, int W, int precision, void* workspace, size_t workspace_bytes,
+                      void* stream)
+{
+    if (!ctx || !frame1 || !frame2 || !out || !workspace)
+        return fail(FIUNET_ERR_INVALID_ARG, "NULL argument");
+    const size_t base = fiunet_workspace_bytes(ctx, B, H, W, precision);
+    if (!base) return fail(H < 16 || W < 16 ? FIUNET_ERR_BAD_SHAPE : FIUNET_ERR_INVALID_ARG, "bad shape");
+    const size_t n = (size_t)B * ctx->cf * H * W, fb = align256(n * 4);
+    if (workspace_bytes < base + 3 * fb) return fail(FIUNET_ERR_WORKSPACE, "workspace too small");
+    char* ws = (char*)workspace;
+    float* a = (float*)(ws + base);
+    float* b = (float*)(ws + base + fb);
+    float* o = (float*)(ws + base + 2 * fb);
+    int rc;
+    if ((rc = fiunet_preprocess_u8(frame1, a, n, stream))) return rc;
+    if ((rc = fiunet_preprocess_u8(frame2, b, n, stream))) return rc;
+    if ((rc = fiunet_forward(ctx, a, b, o, B, H, W, precision, workspace, base, stream))) return rc;
+    return fiunet_postprocess_u8(o, out, n, stream);
+}
+
+int fiunet_preprocess_u8(const uint8_t* in, float* out, size_t n, void* stream)
+{
+    if (!in || !out) return fail(FIUNET_ERR_INVALID_ARG, "NULL argument");
+    if (!n) return FIUNET_OK;
+    hipLaunchKernelGGL(preprocess_u8_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, in, out, n);
+    HIP_TRY(hipGetLastError());
+    return FIUNET_OK;
+}
+
+int fiunet_postprocess_u8(const float* in, uint8_t* out, size_t n, void* stream)
+{
+    if (!in || !out) return fail(FIUNET_ERR_INVALID_ARG, "NULL argument");
+    if (!n) return FIUNET_OK;
+    hipLaunchKernelGGL(postprocess_u8_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, in, out, n);
+    HIP_TRY(hipGetLastError());
+    return FIUNET_OK;
+}
+
+int fiunet_debug_read_activation(fiunet_ctx* ctx, const void* workspace, int B, int H, int W,
+                                 int precision, int tap, float* dst, int out_dims[3], void* stream)
+{
+    if (!ctx || !workspace || !dst || tap < 0 || tap >= NCONV)
+        return fail(FIUNET_ERR_INVALID_ARG, "bad argument");
+    Plan p;
+    if (!make_plan(B, H, W, precision, p)) return fail(FIUNET_ERR_BAD_SHAPE, "bad shape");
+    const int C = kCout[tap], h = p.hs[kLevel[tap]], w = p.ws[kLevel[tap]];
+    if (out_dims) { out_dims[0] = C; out_dims[1] = h; out_dims[2] = w; }
+    const size_t n = (size_t)B * C * h * w;
+    const char* src = (const char*)workspace + p.act_off[tap];
+    if (precision == FIUNET_BF16)
+        hipLaunchKernelGGL((nhwc_to_nchw_f32_kernel<__bf16>), dim3(grid_for(n)), dim3(256), 0,
+                           (hipStream_t)stream, (const __bf16*)src, dst, B, C, h, w);
+    else
+        hipLaunchKernelGGL((nhwc_to_nchw_f32_kernel<float>), dim3(grid_for(n)), dim3(256), 0,
+                           (hipStream_t)stream, (const float*)src, dst, B, C, h, w);
+    HIP_TRY(hipGetLastError());
+    return FIUNET_OK;
+}
+
+}  // extern "C"

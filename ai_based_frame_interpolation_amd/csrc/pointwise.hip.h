@@ -1,0 +1,169 @@
+// pointwise.hip.h -- the HBM-bound kernels of the UNet forward, gfx950 only.
+//
+//   conv3x3_first_kernel   : the Cin = 2*cf (2 or 6) stem conv + BN + ReLU, fp32 VALU arithmetic
+//                            (K = 18 is too thin for MFMA and the layer is write-bound)
+//                            -- /root/reference/model/unet.py:72 (inc.double_conv.0..2)
+//   maxpool2_kernel        : MaxPool2d(2), NHWC (ablation path; normally fused into the conv gather)
+//                            -- unet.py:28
+//   upcat_kernel           : Upsample(x2, bilinear, align_corners=True) + F.pad + cat([skip, up])
+//                            (ablation path; normally fused) -- unet.py:46-54
+//   head1x1_kernel         : OutConv 1x1 + bias, NHWC in -> fp32 NCHW out (ablation path; normally
+//                            fused into the epilogue of up4.conv.double_conv.3) -- unet.py:60
+//   nhwc_to_nchw_f32_kernel: parity-test readback of an intermediate activation
+//   pre/postprocess kernels: model/inference.py:31-35 and :54-61 on device
+#pragma once
+#include "conv3x3_mfma.hip.h"
+
+namespace fiunet {
+
+// One thread = one output pixel x 64 couts.  Weights [9][2*CF][64] are wave-uniform, so the
+// compiler keeps them on the scalar path (s_load + SGPR operand of v_fma).
+template <typename T, int CF>
+__global__ __launch_bounds__(256) void conv3x3_first_kernel(
+    const float* __restrict__ f1, const float* __restrict__ f2, const float* __restrict__ w,
+    const float* __restrict__ scale, const float* __restrict__ shift, T* __restrict__ dst, int B,
+    int H, int W)
+{
+    const int x = blockIdx.x * 256 + threadIdx.x;
+    const int y = blockIdx.y, b = blockIdx.z;
+    if (x >= W) return;
+    float in[9][2 * CF];
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) {
+            const int yy = y + ky - 1, xx = x + kx - 1;
+            const bool ok = yy >= 0 && yy < H && xx >= 0 && xx < W;
+#pragma unroll
+            for (int c = 0; c < CF; ++c) {
+                const size_t o = (((size_t)b * CF + c) * H + yy) * W + xx;
+                in[ky * 3 + kx][c] = ok ? f1[o] : 0.f;        // cat([frame1, frame2], dim=1):
+                in[ky * 3 + kx][CF + c] = ok ? f2[o] : 0.f;   // unet.py:109
+            }
+        }
+    T* o = dst + (((size_t)b * H + y) * W + x) * 64;
+#pragma unroll
+    for (int cb = 0; cb < 64; cb += 16) {
+        float acc[16];
+#pragma unroll
+        for (int c = 0; c < 16; ++c) acc[c] = 0.f;
+#pragma unroll
+        for (int k = 0; k < 9; ++k)
+#pragma unroll
+            for (int ci = 0; ci < 2 * CF; ++ci)
+#pragma unroll
+                for (int c = 0; c < 16; ++c)
+                    acc[c] = fmaf(in[k][ci], w[(k * 2 * CF + ci) * 64 + cb + c], acc[c]);
+#pragma unroll
+        for (int c = 0; c < 16; ++c) acc[c] = fmaxf(acc[c] * scale[cb + c] + shift[cb + c], 0.f);
+        constexpr int NE = Elem<T>::NE;
+#pragma unroll
+        for (int c = 0; c < 16; c += NE)
+            *reinterpret_cast<uint4*>(o + cb + c) = chunk_pack<T>(acc + c);
+    }
+}
+
+// thread = (output pixel, 16-byte channel chunk)
+template <typename T>
+__global__ __launch_bounds__(256) void maxpool2_kernel(const T* __restrict__ src,
+                                                       T* __restrict__ dst, int B, int H, int W,
+                                                       int C)  // H,W = input size
+{
+    const int Ho = H / 2, Wo = W / 2, cpp = C * (int)sizeof(T) / 16;
+    const size_t total = (size_t)B * Ho * Wo * cpp;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        const int ch = (int)(i % cpp);
+        size_t p = i / cpp;
+        const int x = (int)(p % Wo); p /= Wo;
+        const int y = (int)(p % Ho);
+        const int b = (int)(p / Ho);
+        const char* s = (const char*)src + (((size_t)b * H + 2 * y) * W + 2 * x) * C * sizeof(T) + ch * 16;
+        const size_t pxb = (size_t)C * sizeof(T), rowb = (size_t)W * pxb;
+        const uint4 r = chunk_max4<T>(ldg16(s), ldg16(s + pxb), ldg16(s + rowb), ldg16(s + rowb + pxb));
+        *reinterpret_cast<uint4*>((char*)dst + i * 16) = r;
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void upcat_kernel(const ConvArgs a, T* __restrict__ dst)
+{
+    const int C = a.C0 + a.C1, cpp = C * (int)sizeof(T) / 16;
+    const size_t total = (size_t)a.B * a.H * a.W * cpp;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        const int cc = (int)(i % cpp);
+        size_t p = i / cpp;
+        const int x = (int)(p % a.W); p /= a.W;
+        const int y = (int)(p % a.H);
+        const int b = (int)(p / a.H);
+        const uint4 v = gather_chunk<T, SRC_CONCAT_UP>(a, b, y, x, cc >> 2, cc & 3);
+        *reinterpret_cast<uint4*>((char*)dst + i * 16) = v;
+    }
+}
+
+// thread = pixel; reads 64 channels, writes nc fp32 planes
+template <typename T>
+__global__ __launch_bounds__(256) void head1x1_kernel(const T* __restrict__ src,
+                                                      const float* __restrict__ w,
+                                                      const float* __restrict__ bias,
+                                                      float* __restrict__ out, int B, int H, int W,
+                                                      int nc)
+{
+    const size_t HW = (size_t)H * W, total = (size_t)B * HW;
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= total) return;
+    constexpr int NE = Elem<T>::NE;
+    float acc[3] = {0.f, 0.f, 0.f};
+    const char* s = (const char*)(src + i * 64);
+#pragma unroll
+    for (int c = 0; c < 64; c += NE) {
+        float f[NE];
+        chunk_unpack<T>(ldg16(s + c * sizeof(T)), f);
+#pragma unroll
+        for (int k = 0; k < 3; ++k)
+            if (k < nc) {
+#pragma unroll
+                for (int j = 0; j < NE; ++j) acc[k] = fmaf(f[j], w[k * 64 + c + j], acc[k]);
+            }
+    }
+    const size_t b = i / HW, p = i - b * HW;
+    for (int k = 0; k < nc; ++k) out[(b * nc + k) * HW + p] = acc[k] + bias[k];
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void nhwc_to_nchw_f32_kernel(const T* __restrict__ src,
+                                                               float* __restrict__ dst, int B,
+                                                               int C, int H, int W)
+{
+    const size_t total = (size_t)B * C * H * W;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        size_t p = i;
+        const int x = (int)(p % W); p /= W;
+        const int y = (int)(p % H); p /= H;
+        const int c = (int)(p % C);
+        const int b = (int)(p / C);
+        dst[i] = (float)src[(((size_t)b * H + y) * W + x) * C + c];
+    }
+}
+
+// model/inference.py:31-35: image.astype(float32) / 255.0 ; 2.0 * image - 1.0
+__global__ __launch_bounds__(256) void preprocess_u8_kernel(const uint8_t* __restrict__ in,
+                                                            float* __restrict__ out, size_t n)
+{
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+        const float v = __fdiv_rn((float)in[i], 255.0f);
+        out[i] = __fsub_rn(__fmul_rn(2.0f, v), 1.0f);
+    }
+}
+
+// model/inference.py:54-61: (x + 1) / 2 ; clamp(0, 1) ; (x * 255).astype(uint8) -- truncation
+__global__ __launch_bounds__(256) void postprocess_u8_kernel(const float* __restrict__ in,
+                                                             uint8_t* __restrict__ out, size_t n)
+{
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+        float v = __fdiv_rn(__fadd_rn(in[i], 1.0f), 2.0f);
+        v = fminf(fmaxf(v, 0.0f), 1.0f);
+        out[i] = (uint8_t)(int)__fmul_rn(v, 255.0f);
+    }
+}
+
+}  // namespace fiunet

@@ -1,0 +1,223 @@
+"""Host-side counterpart of the reference's model/inference.py hot-path helpers.
+
+Same names, argument meaning and error behaviour as the reference functions they replace:
+  preprocess_image   /root/reference/model/inference.py:11-41
+  postprocess_image  /root/reference/model/inference.py:43-63
+  load_model         /root/reference/model/inference.py:65-99
+  interpolate_frames /root/reference/model/inference.py:101-122
+  generate_multiple_intermediate_frames  inference.py:124-149
+plus the `FrameInterpolator` class that the reference's main.py imports (main.py:100,122) but
+never defines: `.interpolate_frames(img1, img2)` and
+`.interpolate_video(input, output, factor)`.
+
+The arithmetic of pre/post-processing and the network runs in HIP kernels; this file is
+plumbing (file I/O, shapes, batching).  No cv2/imageio in this image, so image files are read
+through cv2 only if it happens to be importable; `.npy` arrays and binary PGM/PPM are always
+supported, and videos are raw `.npy` frame stacks [N,H,W] / [N,H,W,3] uint8.
+"""
+from __future__ import annotations
+
+import os
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+from . import _native
+from .unet import FrameInterpolationUNet
+
+
+def _read_gray(path: str) -> np.ndarray:
+    ext = os.path.splitext(path)[1].lower()
+    if ext == ".npy":
+        img = np.load(path)
+    elif ext in (".pgm", ".ppm"):
+        with open(path, "rb") as f:
+            data = f.read()
+        tok, pos = [], 0
+        while len(tok) < 4:  # magic, width, height, maxval
+            while data[pos:pos + 1].isspace():
+                pos += 1
+            if data[pos:pos + 1] == b"#":
+                pos = data.index(b"\n", pos) + 1
+                continue
+            end = pos
+            while not data[end:end + 1].isspace():
+                end += 1
+            tok.append(data[pos:end]); pos = end
+        pos += 1
+        w, h = int(tok[1]), int(tok[2])
+        ch = 3 if tok[0] == b"P6" else 1
+        img = np.frombuffer(data, dtype=np.uint8, count=w * h * ch, offset=pos).reshape(h, w, ch)
+        img = img[..., 0] if ch == 1 else img
+    else:
+        try:
+            import cv2  # type: ignore
+        except ImportError:
+            return None
+        return cv2.imread(path, cv2.IMREAD_GRAYSCALE)
+    if img.ndim == 3:  # cv2's BGR->GRAY weights are for decoded colour files; here: RGB mean
+        img = np.round(img[..., :3].astype(np.float32) @ np.array([0.299, 0.587, 0.114], np.float32))
+    return np.clip(img, 0, 255).astype(np.uint8)
+
+
+def _resize_linear_u8(img: np.ndarray, target_size) -> np.ndarray:
+    """cv2.resize(img, (W, H)) default INTER_LINEAR: half-pixel centres, edge clamp, result
+    rounded to uint8.  Host glue, not part of the device hot path."""
+    tw, th = int(target_size[0]), int(target_size[1])
+    if img.shape[0] == th and img.shape[1] == tw:
+        return img
+    t = torch.from_numpy(img.astype(np.float32))[None, None]
+    r = F.interpolate(t, size=(th, tw), mode="bilinear", align_corners=False)
+    return r[0, 0].round().clamp(0, 255).to(torch.uint8).numpy()
+
+
+def preprocess_image(image_path, target_size=(256, 256)):
+    """Gray read -> resize to target_size (width, height) -> /255 -> 2x-1 -> [1,1,H,W] fp32.
+
+    Accepts a path (reference behaviour, inference.py:23) or an already decoded uint8 array.
+    Raises ValueError("Could not read image from ...") like inference.py:25-26."""
+    if isinstance(image_path, np.ndarray):
+        image = image_path
+    else:
+        image = _read_gray(image_path) if os.path.exists(str(image_path)) else None
+        if image is None:
+            raise ValueError(f"Could not read image from {image_path}")
+    if target_size is not None:
+        image = _resize_linear_u8(image, target_size)
+    image = image.astype(np.float32) / 255.0
+    image = 2.0 * image - 1.0
+    return torch.from_numpy(image).unsqueeze(0).unsqueeze(0)
+
+
+def postprocess_image(tensor: torch.Tensor) -> np.ndarray:
+    """[-1,1] fp32 tensor -> uint8 image: (x+1)/2, clamp [0,1], *255, truncating cast
+    (inference.py:54-61).  Runs the HIP post-processing kernel; the tensor must be on the GPU
+    (interpolate_frames returns it there)."""
+    if not tensor.is_cuda:
+        raise RuntimeError("postprocess_image (MI355X build) expects the device tensor that "
+                           "interpolate_frames returned; there is no CPU fallback")
+    t = tensor.detach().to(torch.float32).contiguous()
+    return _native.postprocess_u8(t).squeeze().cpu().numpy()
+
+
+def load_model(model_path, device, precision=None, frame_channels=1):
+    """Construct bilinear=True, load `{'model_state_dict': ...}` or a bare state-dict, move to
+    device, eval (inference.py:77-97).  FileNotFoundError if the file is missing (:80-81)."""
+    model = FrameInterpolationUNet(bilinear=True, frame_channels=frame_channels, precision=precision)
+    if not os.path.exists(model_path):
+        raise FileNotFoundError(f"Model file not found: {model_path}")
+    checkpoint = torch.load(model_path, map_location="cpu")
+    if "model_state_dict" in checkpoint:
+        model.load_state_dict(checkpoint["model_state_dict"])
+        print(f"Model loaded from {model_path}")
+        print(f"Trained for {checkpoint.get('epoch', 'Unknown')} epochs")
+        val = checkpoint.get("val_loss", "Unknown")
+        print(f"Best validation loss: {val:.6f}" if isinstance(val, float) else
+              f"Best validation loss: {val}")
+    else:
+        model.load_state_dict(checkpoint)
+        print(f"Model state dict loaded from {model_path}")
+    model = model.to(device)
+    model.eval()
+    return model
+
+
+def interpolate_frames(model, frame1, frame2, device):
+    """inference.py:115-120: move to device, no_grad, model(frame1, frame2)."""
+    frame1 = frame1.to(device)
+    frame2 = frame2.to(device)
+    with torch.no_grad():
+        return model(frame1, frame2)
+
+
+def generate_multiple_intermediate_frames(model, frame1, frame2, num_intermediate, device):
+    """inference.py:124-149: the reference runs the SAME pair N times (the network has no time
+    input), so all N frames are identical; one forward is enough."""
+    frame = interpolate_frames(model, frame1, frame2, device)
+    return [frame for _ in range(num_intermediate)]
+
+
+def _pair_batches(n_pairs: int, batch: int):
+    for s in range(0, n_pairs, batch):
+        yield s, min(batch, n_pairs - s)
+
+
+@torch.no_grad()
+def interpolate_sequence(model, frames_u8: torch.Tensor, batch: int = 8) -> torch.Tensor:
+    """factor-2 video loop on one GPU: device uint8 frames [N,H,W] (or [N,C,H,W]) ->
+    [2N-1, ...] = F0, M0, F1, M1, ..., F(N-1), where Mi = model(Fi, Fi+1) through the fused
+    uint8 path (pre/post-processing on device).  Semantics per SURVEY.md 8a row 11."""
+    squeeze = frames_u8.dim() == 3
+    fr = frames_u8.unsqueeze(1) if squeeze else frames_u8
+    n = fr.shape[0]
+    out = torch.empty((2 * n - 1,) + tuple(fr.shape[1:]), dtype=torch.uint8, device=fr.device)
+    out[0::2] = fr
+    for s, cnt in _pair_batches(n - 1, batch):
+        out[2 * s + 1: 2 * (s + cnt): 2] = model.forward_u8(fr[s:s + cnt], fr[s + 1:s + cnt + 1])
+    return out.squeeze(1) if squeeze else out
+
+
+class FrameInterpolator:
+    """What main.py:95-129 expects from `model.inference` (it is missing in the reference).
+
+    interpolate_frames(img1, img2): uint8 [H,W] (gray) or [H,W,3] images -> uint8 image of the
+    same shape; colour images are processed per channel with the 2->1 grayscale network unless
+    the checkpoint is the 6->3 variant.
+    interpolate_video(input_path, output_path, factor=2): raw .npy frame stack in/out;
+    factor must be a power of two (recursive bisection; factor 2 is the only semantics the
+    reference's flags imply, main.py:57-62)."""
+
+    def __init__(self, model_path=None, device="cuda", precision=None, model=None, batch=8):
+        self.device = torch.device("cuda" if device in ("auto", None) else device)
+        self.model = model if model is not None else load_model(model_path, self.device, precision)
+        self.batch = batch
+
+    def _as_planes(self, img: np.ndarray) -> torch.Tensor:
+        t = torch.from_numpy(np.ascontiguousarray(img)).to(self.device)
+        if t.dim() == 2:
+            return t[None, None]
+        planes = t.permute(2, 0, 1)  # [C,H,W]
+        return planes[None] if self.model.frame_channels == planes.shape[0] else planes[:, None]
+
+    def interpolate_frames(self, img1: np.ndarray, img2: np.ndarray) -> np.ndarray:
+        if img1.shape != img2.shape or img1.dtype != np.uint8:
+            raise ValueError("expected two uint8 images of equal shape")
+        a, b = self._as_planes(img1), self._as_planes(img2)
+        o = self.model.forward_u8(a, b)
+        if img1.ndim == 2:
+            return o[0, 0].cpu().numpy()
+        o = o[0] if self.model.frame_channels == img1.shape[2] else o[:, 0]
+        return o.permute(1, 2, 0).contiguous().cpu().numpy()
+
+    def interpolate_video(self, input_path, output_path, factor=2):
+        if factor < 2 or factor & (factor - 1):
+            raise ValueError("factor must be a power of two (the network has no time input)")
+        if not os.path.exists(input_path):
+            raise FileNotFoundError(f"Video file not found: {input_path}")
+        frames = np.load(input_path)
+        if frames.dtype != np.uint8 or frames.ndim not in (3, 4):
+            raise ValueError("expected a uint8 .npy stack [N,H,W] or [N,H,W,3]")
+        t = torch.from_numpy(frames).to(self.device)
+        if t.dim() == 4:
+            t = t.permute(0, 3, 1, 2).contiguous()
+            if self.model.frame_channels == 1:  # per-channel application of the 2->1 network
+                n, c, h, w = t.shape
+                t = t.permute(1, 0, 2, 3).reshape(c * n, h, w)
+                outs = []
+                for ci in range(c):
+                    seq = t[ci * n:(ci + 1) * n]
+                    f = factor
+                    while f > 1:
+                        seq = interpolate_sequence(self.model, seq, self.batch); f //= 2
+                    outs.append(seq)
+                res = torch.stack(outs, dim=-1)
+                np.save(output_path, res.cpu().numpy())
+                return res.shape[0]
+        f = factor
+        while f > 1:
+            t = interpolate_sequence(self.model, t, self.batch); f //= 2
+        if t.dim() == 4:
+            t = t.permute(0, 2, 3, 1)
+        np.save(output_path, t.cpu().numpy())
+        return t.shape[0]

@@ -1,0 +1,222 @@
+"""Drop-in mirror of the reference's model/unet.py for the MI355X HIP path.
+
+Same class name, constructor, call signature, attribute tree and state-dict schema as
+/root/reference/model/unet.py:97-112 (`FrameInterpolationUNet`) and :65-95 (`UNet`), so
+`load_state_dict` of a reference `best_model.pth` works and callers such as
+model/inference.py:77-97,120 need no change.  The forward itself does not run any torch op
+on the data: it hands raw device pointers to the hand-written HIP kernels behind the C ABI
+(include/fiunet.h).  PyTorch only provides device memory, the stream and the parameter
+containers (nn.Conv2d / nn.BatchNorm2d objects are used purely as named parameter holders
+so that initialisation and state-dict keys are identical to the reference's; they are never
+called).
+
+There is no CPU fallback: CPU tensors, train mode and a missing/unbuilt extension raise.
+"""
+from __future__ import annotations
+
+import os
+
+import torch
+import torch.nn as nn
+
+from . import _native
+
+# ---- layer table (unet.py:72-82, bilinear=True) ----------------------------------------------
+# (attribute path of the DoubleConv holder, in, mid, out)
+_ENCODER = (("down1", 64, 128), ("down2", 128, 256), ("down3", 256, 512), ("down4", 512, 512))
+_DECODER = (("up1", 1024, 256), ("up2", 512, 128), ("up3", 256, 64), ("up4", 128, 64))
+
+#: channels / pyramid level of the 18 conv+BN+ReLU outputs, in state-dict order (debug taps)
+TAP_CHANNELS = (64, 64, 128, 128, 256, 256, 512, 512, 512, 512, 512, 256, 256, 128, 128, 64, 64, 64)
+TAP_LEVEL = (0, 0, 1, 1, 2, 2, 3, 3, 4, 4, 3, 3, 2, 2, 1, 1, 0, 0)
+TAP_NAMES = tuple(
+    f"{p}.double_conv.{c}"
+    for p in ("unet.inc", "unet.down1.maxpool_conv.1", "unet.down2.maxpool_conv.1",
+              "unet.down3.maxpool_conv.1", "unet.down4.maxpool_conv.1", "unet.up1.conv",
+              "unet.up2.conv", "unet.up3.conv", "unet.up4.conv")
+    for c in (0, 3))
+
+_PRECISIONS = {"fp32": _native.FP32, "float32": _native.FP32, "bf16": _native.BF16,
+               "bfloat16": _native.BF16}
+
+
+class _Holder(nn.Module):
+    """Parameter container; exists only to give parameters the reference's names."""
+
+    def forward(self, *a, **k):  # pragma: no cover
+        raise RuntimeError("parameter holder: the forward runs in the HIP kernels, not in torch")
+
+
+def _double_conv(cin: int, cout: int, mid: int | None = None) -> _Holder:
+    """Holder with `.double_conv.{0,1,3,4}` like DoubleConv (unet.py:5-18); slots 2 and 5
+    (ReLU) own no tensors."""
+    mid = mid or cout
+    h = _Holder()
+    h.double_conv = nn.ModuleDict({
+        "0": nn.Conv2d(cin, mid, kernel_size=3, padding=1, bias=False),
+        "1": nn.BatchNorm2d(mid),
+        "3": nn.Conv2d(mid, cout, kernel_size=3, padding=1, bias=False),
+        "4": nn.BatchNorm2d(cout),
+    })
+    return h
+
+
+class UNet(_Holder):
+    """Parameter tree of the reference UNet (unet.py:65-82); widths 64-128-256-512-512."""
+
+    def __init__(self, n_channels: int = 2, n_classes: int = 1, bilinear: bool = False):
+        super().__init__()
+        self.n_channels = n_channels
+        self.n_classes = n_classes
+        self.bilinear = bilinear
+        if not bilinear:
+            raise NotImplementedError(
+                "bilinear=False (ConvTranspose2d decoder, unet.py:42-44) is not built for the "
+                "MI355X path; every reference caller constructs bilinear=True (inference.py:77)")
+        self.inc = _double_conv(n_channels, 64)
+        for name, cin, cout in _ENCODER:
+            d = _Holder()
+            d.maxpool_conv = nn.ModuleDict({"1": _double_conv(cin, cout)})
+            setattr(self, name, d)
+        for name, cin, cout in _DECODER:
+            u = _Holder()
+            u.conv = _double_conv(cin, cout, cin // 2)
+            setattr(self, name, u)
+        self.outc = _Holder()
+        self.outc.conv = nn.Conv2d(64, n_classes, kernel_size=1)
+
+
+class FrameInterpolationUNet(nn.Module):
+    """`model(frame1, frame2)` -> middle frame; see module docstring.
+
+    Extra (non-reference) keyword arguments:
+      frame_channels: 1 (grayscale, the reference's 2->1 network) or 3 (RGB 6->3 variant the
+                      reference README describes); same kernels.
+      precision:      "fp32" (default; exact-fp32 MFMA, |d| <= 1e-3 contract) or "bf16"
+                      (bf16 storage + MFMA, fp32 accumulate).  Env FIUNET_PRECISION overrides.
+    """
+
+    def __init__(self, bilinear: bool = False, frame_channels: int = 1, precision: str | None = None):
+        super().__init__()
+        self.unet = UNet(n_channels=2 * frame_channels, n_classes=frame_channels, bilinear=bilinear)
+        self.frame_channels = frame_channels
+        self.precision = precision or os.environ.get("FIUNET_PRECISION", "fp32")
+        if self.precision not in _PRECISIONS:
+            raise ValueError(f"precision must be one of {sorted(_PRECISIONS)}")
+        self._ctx = None          # _native.Context, per device
+        self._ctx_dirty = True    # weights on the device are stale w.r.t. the parameters
+        self._ws = None           # cached workspace tensor
+        self._ws_key = None
+        self._options = 0
+
+    # -- keep the device copy of the weights in sync with the nn.Module state --------------
+    def _apply(self, fn, *a, **k):
+        self._ctx_dirty = True
+        return super()._apply(fn, *a, **k)
+
+    def load_state_dict(self, *a, **k):
+        self._ctx_dirty = True
+        return super().load_state_dict(*a, **k)
+
+    def refresh_weights(self):
+        """Call after editing parameters in place so the next forward re-uploads them."""
+        self._ctx_dirty = True
+
+    def set_options(self, *, unfused: bool = False, keep_all: bool = False):
+        self._options = (_native.OPT_UNFUSED if unfused else 0) | (_native.OPT_KEEP_ALL if keep_all else 0)
+        if self._ctx is not None:
+            self._ctx.set_options(self._options)
+
+    def _context(self, device: torch.device) -> "_native.Context":
+        idx = device.index if device.index is not None else torch.cuda.current_device()
+        if self._ctx is None or self._ctx.device_index != idx:
+            if self._ctx is not None:
+                self._ctx.close()
+            self._ctx = _native.Context(idx, self.frame_channels, True)
+            self._ctx_dirty = True
+        if self._ctx_dirty:
+            self._ctx.load_state_dict(self.state_dict())
+            self._ctx.set_options(self._options)
+            self._ctx_dirty = False
+        return self._ctx
+
+    def _workspace(self, ctx, device, b, h, w, prec, u8=False):
+        key = (device, b, h, w, prec, u8)
+        if self._ws_key != key:
+            self._ws = None  # release before allocating the next one
+            nbytes = ctx.workspace_bytes(b, h, w, prec, u8)
+            self._ws = torch.empty(nbytes, dtype=torch.uint8, device=device)
+            self._ws_key = key
+        return self._ws
+
+    def _check_pair(self, frame1, frame2, dtype_ok):
+        if frame1.dim() != 4 or frame1.shape != frame2.shape:
+            raise RuntimeError(
+                f"expected two [B,{self.frame_channels},H,W] tensors of equal shape, got "
+                f"{tuple(frame1.shape)} and {tuple(frame2.shape)}")
+        if frame1.shape[1] != self.frame_channels:
+            raise RuntimeError(
+                f"expected {self.frame_channels} channel(s) per frame, got {frame1.shape[1]}")
+        if not frame1.is_cuda or not frame2.is_cuda:
+            raise RuntimeError(
+                "FrameInterpolationUNet (MI355X build) runs only on a HIP device: move the model "
+                "and the frames with .to('cuda').  There is no CPU fallback in this package.")
+        if self.training:
+            raise RuntimeError(
+                "inference-only build: call model.eval() first (reference: inference.py:97); "
+                "train-mode BatchNorm (batch statistics) is not implemented")
+        if frame1.dtype not in dtype_ok or frame2.dtype != frame1.dtype:
+            raise RuntimeError(f"unsupported frame dtype {frame1.dtype}/{frame2.dtype}")
+
+    @torch.no_grad()
+    def forward(self, frame1: torch.Tensor, frame2: torch.Tensor) -> torch.Tensor:
+        self._check_pair(frame1, frame2, (torch.float32, torch.float16, torch.bfloat16, torch.float64))
+        in_dtype = frame1.dtype
+        f1 = frame1.to(torch.float32).contiguous()
+        f2 = frame2.to(torch.float32).contiguous()
+        b, _, h, w = f1.shape
+        prec = _PRECISIONS[self.precision]
+        ctx = self._context(f1.device)
+        ws = self._workspace(ctx, f1.device, b, h, w, prec)
+        out = torch.empty_like(f1)
+        with torch.cuda.device(f1.device):
+            ctx.forward(f1, f2, out, prec, ws)
+        return out if in_dtype == torch.float32 else out.to(in_dtype)
+
+    @torch.no_grad()
+    def forward_u8(self, frame1: torch.Tensor, frame2: torch.Tensor) -> torch.Tensor:
+        """uint8 [B,C,H,W] frames in -> uint8 interpolated frame, with the reference's
+        pre/post-processing (inference.py:31-35, :54-61) on device."""
+        self._check_pair(frame1, frame2, (torch.uint8,))
+        f1, f2 = frame1.contiguous(), frame2.contiguous()
+        b, _, h, w = f1.shape
+        prec = _PRECISIONS[self.precision]
+        ctx = self._context(f1.device)
+        ws = self._workspace(ctx, f1.device, b, h, w, prec, u8=True)
+        out = torch.empty_like(f1)
+        with torch.cuda.device(f1.device):
+            ctx.forward_u8(f1, f2, out, prec, ws)
+        return out
+
+    @torch.no_grad()
+    def debug_activations(self, frame1, frame2, taps=None):
+        """Parity-test hook: run one forward keeping every stage and return
+        ({tap name: fp32 NCHW tensor}, output)."""
+        saved = self._options
+        self.set_options(unfused=bool(saved & _native.OPT_UNFUSED), keep_all=True)
+        try:
+            out = self.forward(frame1, frame2)
+            b, _, h, w = frame1.shape
+            prec = _PRECISIONS[self.precision]
+            acts = {}
+            for t in (range(18) if taps is None else taps):
+                acts[TAP_NAMES[t]] = self._ctx.read_activation(self._ws, b, h, w, prec, t)
+        finally:
+            self._options = saved
+            self._ctx.set_options(saved)
+        return acts, out
+
+
+def count_parameters(model: nn.Module) -> int:
+    """unet.py:114-116."""
+    return sum(p.numel() for p in model.parameters() if p.requires_grad)

@@ -1,0 +1,114 @@
+/*
+ * fiunet.h -- C ABI of the MI355X-native UNet frame-pair forward (libfiunet_hip.so).
+ *
+ * The reference (daultanigaurav/AI-BASED-FRAME-INTERPOLATION) has no FFI / plugin layer: its
+ * boundary for this path is a Python class plus a state-dict.  Each entry
+ * point below therefore replaces a piece of that Python surface, cited as reference file:line.
+ * Plain pointers and sizes only; no torch types; every function returns an int status
+ * (0 == FIUNET_OK) and never throws across the ABI.  Device pointers are HIP device memory
+ * of the context's device; `stream` is a hipStream_t passed as void* (NULL = default stream).
+ * All launches are asynchronous on that stream; one in-flight call per ctx+stream.
+ *
+ * See INTEGRATION.md for the reference-side binding (a ctypes stub in model/unet.py).
+ */
+#ifndef FIUNET_H
+#define FIUNET_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define FIUNET_ABI_VERSION 1
+
+enum fiunet_status {
+    FIUNET_OK = 0,
+    FIUNET_ERR_INVALID_ARG = 1,   /* bad pointer / size (the reference raises RuntimeError) */
+    FIUNET_ERR_BAD_SHAPE = 2,     /* H or W < 16 (reference: max-pool raises) */
+    FIUNET_ERR_MISSING_WEIGHT = 3,/* a state-dict tensor is absent or has the wrong numel */
+    FIUNET_ERR_NOT_LOADED = 4,    /* forward before load_weights */
+    FIUNET_ERR_WORKSPACE = 5,     /* workspace too small */
+    FIUNET_ERR_HIP = 6,           /* a HIP runtime call failed; see fiunet_last_error_string */
+    FIUNET_ERR_UNSUPPORTED = 7    /* bilinear=False (ConvTranspose2d variant, unet.py:42-44) */
+};
+
+/* Arithmetic type of the conv path.  FP32: fp32 storage, exact-fp32 MFMA (v_mfma_f32_16x16x4_f32).
+ * BF16: bf16 activations/weights in HBM, v_mfma_f32_16x16x32_bf16 with fp32 accumulation; the
+ * first (Cin=2) conv and the final 1x1 conv stay fp32 arithmetic in both modes. */
+enum fiunet_precision { FIUNET_FP32 = 0, FIUNET_BF16 = 1 };
+
+/* Bit flags for fiunet_set_options. */
+enum fiunet_option {
+    FIUNET_OPT_UNFUSED = 1, /* ablation: run max-pool, upsample+pad+concat and the 1x1 head as
+                               separate kernels instead of fusing them into the consumer conv */
+    FIUNET_OPT_KEEP_ALL = 2 /* also store the last 64-ch activation (tap 17) that the fused 1x1
+                               head otherwise keeps in registers; for fiunet_debug_read_activation */
+};
+
+typedef struct fiunet_ctx fiunet_ctx;
+
+/* Replaces FrameInterpolationUNet.__init__ / UNet.__init__ (model/unet.py:99-103, :66-82).
+ * frame_channels: 1 = grayscale (the reference's 2->1 network), 3 = RGB (6->3, README variant).
+ * bilinear must be 1 (every reference caller passes bilinear=True: model/inference.py:77). */
+int fiunet_create(fiunet_ctx** out_ctx, int device_id, int frame_channels, int bilinear);
+
+/* Replaces nn.Module teardown (Python GC). */
+int fiunet_destroy(fiunet_ctx* ctx);
+
+int fiunet_set_options(fiunet_ctx* ctx, unsigned flags);
+
+/* Replaces model.load_state_dict(...) + .to(device) + .eval() (model/inference.py:83-97).
+ * `names[i]` are reference state-dict keys ("unet.inc.double_conv.0.weight", ...),
+ * `host_ptrs[i]` contiguous fp32 host arrays, `numels[i]` their element counts.  The
+ * `num_batches_tracked` counters may be omitted or passed (ignored).  The library folds the
+ * eval-mode BatchNorm into a per-channel scale/shift, repacks OIHW weights into its kernel
+ * layout for both precisions and owns the device copies. */
+int fiunet_load_weights(fiunet_ctx* ctx, int n, const char* const* names,
+                        const float* const* host_ptrs, const int64_t* numels);
+
+/* Bytes of device scratch fiunet_forward needs for a [B,*,H,W] batch; 0 on bad arguments. */
+size_t fiunet_workspace_bytes(const fiunet_ctx* ctx, int B, int H, int W, int precision);
+
+/* Replaces FrameInterpolationUNet.forward(frame1, frame2) in eval mode
+ * (model/unet.py:105-112 -> :84-95), as called by interpolate_frames (model/inference.py:120).
+ * frame1, frame2: device fp32 [B, frame_channels, H, W] contiguous (NCHW);
+ * out: device fp32 [B, frame_channels, H, W]; raw logits, no activation.
+ * workspace: device scratch of at least fiunet_workspace_bytes(...), 256-B aligned. */
+int fiunet_forward(fiunet_ctx* ctx, const float* frame1, const float* frame2, float* out, int B,
+                   int H, int W, int precision, void* workspace, size_t workspace_bytes,
+                   void* stream);
+
+/* Video-path variant: uint8 frames in, uint8 interpolated frame out, with the reference's
+ * pre/post-processing fused on device: x/255*2-1 (model/inference.py:31-35) and
+ * trunc(clamp((y+1)/2,0,1)*255) (model/inference.py:54-61).  frame1/2, out: device uint8
+ * [B, frame_channels, H, W].  Needs workspace of fiunet_workspace_bytes + 3*B*C*H*W*4 bytes
+ * (use fiunet_workspace_bytes_u8). */
+size_t fiunet_workspace_bytes_u8(const fiunet_ctx* ctx, int B, int H, int W, int precision);
+int fiunet_forward_u8(fiunet_ctx* ctx, const uint8_t* frame1, const uint8_t* frame2, uint8_t* out,
+                      int B, int H, int W, int precision, void* workspace, size_t workspace_bytes,
+                      void* stream);
+
+/* Replaces preprocess_image's arithmetic (model/inference.py:31-35): out = 2*(in/255) - 1. */
+int fiunet_preprocess_u8(const uint8_t* in, float* out, size_t n, void* stream);
+/* Replaces postprocess_image's arithmetic (model/inference.py:54-61), truncating cast. */
+int fiunet_postprocess_u8(const float* in, uint8_t* out, size_t n, void* stream);
+
+/* Parity-test hook: after a fiunet_forward on `workspace`, convert one intermediate activation
+ * (NHWC in the compute precision) to fp32 NCHW at dst.  tap = 2*block + conv for the 18 fused
+ * conv+BN+ReLU stages in state-dict order (0 = unet.inc.double_conv.0 ... 17 =
+ * unet.up4.conv.double_conv.3).  out_dims receives {C, H, W} of that activation. */
+int fiunet_debug_read_activation(fiunet_ctx* ctx, const void* workspace, int B, int H, int W,
+                                 int precision, int tap, float* dst, int out_dims[3],
+                                 void* stream);
+
+/* Thread-local description of the last non-OK status. */
+const char* fiunet_last_error_string(void);
+
+int fiunet_abi_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FIUNET_H */
