@@ -29,7 +29,8 @@ SYMBOLS = (
     "fiunet_abi_version", "fiunet_last_error_string", "fiunet_create", "fiunet_destroy",
     "fiunet_set_options", "fiunet_load_weights", "fiunet_workspace_bytes", "fiunet_forward",
     "fiunet_workspace_bytes_u8", "fiunet_forward_u8", "fiunet_preprocess_u8",
-    "fiunet_postprocess_u8", "fiunet_debug_read_activation",
+    "fiunet_postprocess_u8", "fiunet_debug_read_activation", "fiunet_profile_enable",
+    "fiunet_profile_read",
 )
 
 _lib = None
@@ -73,6 +74,9 @@ def lib() -> ctypes.CDLL:
     L.fiunet_postprocess_u8.argtypes = [vp, vp, sz, vp]
     L.fiunet_debug_read_activation.argtypes = [vp, vp, ci, ci, ci, ci, ci, vp,
                                                ctypes.POINTER(ci), vp]
+    L.fiunet_profile_enable.argtypes = [vp, ci]
+    L.fiunet_profile_read.argtypes = [vp, ctypes.POINTER(ci), ctypes.POINTER(ctypes.c_float),
+                                      ctypes.POINTER(ctypes.c_double), ctypes.c_char_p, ci]
     for name in SYMBOLS:
         getattr(L, name)  # AttributeError here = the .so does not export what the header declares
     _lib = L
@@ -146,6 +150,23 @@ class Context:
         check(lib().fiunet_forward_u8(self._h, f1.data_ptr(), f2.data_ptr(), out.data_ptr(), b, h,
                                       w, precision, workspace.data_ptr(), workspace.numel(), s),
               "fiunet_forward_u8")
+
+    def profile_enable(self, on: bool):
+        check(lib().fiunet_profile_enable(self._h, 1 if on else 0), "fiunet_profile_enable")
+
+    def profile_read(self):
+        """-> (n_forwards, [(kernel name, avg ms, algorithmic flops)] for the 18 conv stages)"""
+        n = ctypes.c_int(0)
+        ms = (ctypes.c_float * 18)()
+        fl = (ctypes.c_double * 18)()
+        names = ctypes.create_string_buffer(18 * 96)
+        check(lib().fiunet_profile_read(self._h, ctypes.byref(n), ms, fl, names, 96),
+              "fiunet_profile_read")
+        rows = []
+        for i in range(18):
+            nm = names.raw[i * 96:(i + 1) * 96].split(b"\0", 1)[0].decode()
+            rows.append((nm, float(ms[i]), float(fl[i])))
+        return n.value, rows
 
     def read_activation(self, workspace, b, h, w, precision, tap):
         dims = (ctypes.c_int * 3)()

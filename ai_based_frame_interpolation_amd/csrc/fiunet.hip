@@ -107,6 +107,12 @@ struct fiunet_ctx {
     float* head_w = nullptr;  // [cf][64]
     float* head_b = nullptr;  // [cf]
     std::vector<void*> owned;
+    // per-layer HIP-event profiling (fiunet_profile_*): NCONV+1 events per recorded forward
+    bool profiling = false;
+    std::vector<hipEvent_t> ev_pool;
+    size_t ev_used = 0;
+    std::string layer_name[NCONV];
+    double layer_flops[NCONV] = {0};
 };
 
 namespace {
@@ -128,10 +134,18 @@ void free_weights(fiunet_ctx* ctx)
     ctx->loaded = false;
 }
 
+thread_local std::string* g_name_out = nullptr;  // where the next conv launch reports its kernel
+
 template <typename T, int BN, int TH, int TW, int MODE, bool HEAD>
 int launch_conv_cfg(ConvArgs a, hipStream_t s)
 {
     using Tile = ConvTile<BN, TH, TW>;
+    if (g_name_out) {
+        char buf[128];
+        std::snprintf(buf, sizeof buf, "conv3x3_mfma_kernel<%s,%d,%d,%d,%d,%d>",
+                      sizeof(T) == 2 ? "bf16" : "f32", BN, TH, TW, MODE, (int)HEAD);
+        *g_name_out = buf;
+    }
     a.tilesX = (a.W + TW - 1) / TW;
     a.tilesY = (a.H + TH - 1) / TH;
     a.nct = a.Cout / BN;
@@ -192,6 +206,18 @@ int forward_impl(fiunet_ctx* ctx, const float* f1, const float* f2, float* out, 
     auto act = [&](int i) { return (T*)(ws + p.act_off[i]); };
     T* scratch = (T*)(ws + p.scratch_off);
 
+    // optional per-layer timing: event e[0] before the stem, e[i+1] after stage i
+    hipEvent_t* ev = nullptr;
+    if (ctx->profiling) {
+        if (ctx->ev_used + NCONV + 1 > ctx->ev_pool.size()) {
+            const size_t old = ctx->ev_pool.size();
+            ctx->ev_pool.resize(old + 64 * (NCONV + 1));
+            for (size_t k = old; k < ctx->ev_pool.size(); ++k) HIP_TRY(hipEventCreate(&ctx->ev_pool[k]));
+        }
+        ev = ctx->ev_pool.data() + ctx->ev_used;
+        ctx->ev_used += NCONV + 1;
+        HIP_TRY(hipEventRecord(ev[0], s));
+    }
     // conv 0: fp32 stem (unet.py:72, first conv of inc)
     {
         const ConvWeights& cw = ctx->conv[0];
@@ -203,6 +229,12 @@ int forward_impl(fiunet_ctx* ctx, const float* f1, const float* f2, float* out, 
             hipLaunchKernelGGL((conv3x3_first_kernel<T, 3>), grid, dim3(256), 0, s, f1, f2,
                                (const float*)cw.w_f32, cw.scale, cw.shift, act(0), B, H, W);
         HIP_TRY(hipGetLastError());
+        if (ev) {
+            HIP_TRY(hipEventRecord(ev[1], s));
+            ctx->layer_name[0] = std::string("conv3x3_first_kernel<") + (bf16 ? "bf16" : "f32") + "," +
+                                 std::to_string(ctx->cf) + ">";
+            ctx->layer_flops[0] = 2.0 * B * H * W * 9.0 * cw.cin * cw.cout;
+        }
     }
     for (int i = 1; i < NCONV; ++i) {
         const ConvWeights& cw = ctx->conv[i];
@@ -249,14 +281,21 @@ int forward_impl(fiunet_ctx* ctx, const float* f1, const float* f2, float* out, 
             a.head_w = ctx->head_w; a.head_b = ctx->head_b; a.head_out = out; a.head_nc = ctx->cf;
             if (!(ctx->flags & FIUNET_OPT_KEEP_ALL)) a.dst = nullptr;
         }
+        g_name_out = ev ? &ctx->layer_name[i] : nullptr;
         const int rc = launch_conv<T>(a, mode, head, s);
+        g_name_out = nullptr;
         if (rc != FIUNET_OK) return rc;
+        if (ev) {
+            ctx->layer_flops[i] = 2.0 * B * a.H * a.W * 9.0 * cw.cin * cw.cout;
+            if (i < NCONV - 1 || !unfused) HIP_TRY(hipEventRecord(ev[i + 1], s));
+        }
     }
     if (unfused) {
         const size_t n = (size_t)B * H * W;
         hipLaunchKernelGGL((head1x1_kernel<T>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s,
                            (const T*)act(NCONV - 1), ctx->head_w, ctx->head_b, out, B, H, W, ctx->cf);
         HIP_TRY(hipGetLastError());
+        if (ev) HIP_TRY(hipEventRecord(ev[NCONV], s));
     }
     return FIUNET_OK;
 }
@@ -295,6 +334,7 @@ int fiunet_destroy(fiunet_ctx* ctx)
     if (!ctx) return FIUNET_OK;
     (void)hipSetDevice(ctx->device);
     free_weights(ctx);
+    for (hipEvent_t e : ctx->ev_pool) (void)hipEventDestroy(e);
     delete ctx;
     return FIUNET_OK;
 }
@@ -464,6 +504,42 @@ int fiunet_postprocess_u8(const float* in, uint8_t* out, size_t n, void* stream)
     if (!n) return FIUNET_OK;
     hipLaunchKernelGGL(postprocess_u8_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, in, out, n);
     HIP_TRY(hipGetLastError());
+    return FIUNET_OK;
+}
+
+int fiunet_profile_enable(fiunet_ctx* ctx, int enable)
+{
+    if (!ctx) return fail(FIUNET_ERR_INVALID_ARG, "ctx is NULL");
+    ctx->profiling = enable != 0;
+    ctx->ev_used = 0;
+    return FIUNET_OK;
+}
+
+int fiunet_profile_read(fiunet_ctx* ctx, int* n_forwards, float* avg_ms, double* flops,
+                        char* names, int name_stride)
+{
+    if (!ctx || !avg_ms) return fail(FIUNET_ERR_INVALID_ARG, "NULL argument");
+    const size_t nf = ctx->ev_used / (NCONV + 1);
+    if (n_forwards) *n_forwards = (int)nf;
+    for (int i = 0; i < NCONV; ++i) avg_ms[i] = 0.f;
+    for (size_t f = 0; f < nf; ++f) {
+        hipEvent_t* ev = ctx->ev_pool.data() + f * (NCONV + 1);
+        HIP_TRY(hipEventSynchronize(ev[NCONV]));
+        for (int i = 0; i < NCONV; ++i) {
+            float ms = 0.f;
+            HIP_TRY(hipEventElapsedTime(&ms, ev[i], ev[i + 1]));
+            avg_ms[i] += ms;
+        }
+    }
+    for (int i = 0; i < NCONV; ++i) {
+        if (nf) avg_ms[i] /= (float)nf;
+        if (flops) flops[i] = ctx->layer_flops[i];
+        if (names && name_stride > 0) {
+            std::strncpy(names + (size_t)i * name_stride, ctx->layer_name[i].c_str(), name_stride - 1);
+            names[(size_t)i * name_stride + name_stride - 1] = 0;
+        }
+    }
+    ctx->ev_used = 0;
     return FIUNET_OK;
 }
 

@@ -1,0 +1,245 @@
+#!/usr/bin/env python3
+"""bench.py -- interpolated frames/s of the MI355X UNet frame-pair forward.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+A step = one forward of the hot path over one batch of synthetic frame pairs that is already
+resident in HBM.  Default workload = BASELINE.json configs[2]: batch 8 of 1920x1080 pairs, bf16
+MFMA path, one batch per GPU (weak scaling: frame pairs are independent, ranks exchange
+nothing inside the timed region).  Rank 0 prints ONE JSON line.
+
+Extra objects on that line:
+  roofline     -- dominant kernel (by time) of the forward: algorithmic FLOPs per launch / its
+                  average launch duration, measured live with HIP events recorded on the launch
+                  stream between the stages (fiunet_profile_*), vs the dense MFMA peak.
+  cpu_baseline -- the PyTorch-CPU oracle (a port of the reference's forward, pinned to reference
+                  outputs) timed on this box's host cores on ONE 1080p pair (N=1, rank 0 only).
+The oracle is only the baseline/checker here; the measured path never touches it.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import ai_based_frame_interpolation_amd as P  # noqa: E402
+
+PEAK_TFLOPS = {"bf16": 2500.0, "fp32": 157.3}   # MI355X dense MFMA peaks (MI355X_MICROARCH.md)
+PEAK_HBM_GBS = 8000.0
+# fused-ideal HBM elements per frame at HxW: 2146.1 M @1080p, scales with pixels
+ELEMS_PER_PIXEL = 2146.1e6 / (1080 * 1920)
+
+
+def conv_flops(h, w):
+    """2*MAC over the 18 3x3 convs + the 1x1 head, gray 2->1 network."""
+    hs, ws = [h], [w]
+    for _ in range(4):
+        hs.append(hs[-1] // 2); ws.append(ws[-1] // 2)
+    chans = [(2, 64, 64), (64, 128, 128), (128, 256, 256), (256, 512, 512), (512, 512, 512),
+             (1024, 512, 256), (512, 256, 128), (256, 128, 64), (128, 64, 64)]
+    lv = [0, 1, 2, 3, 4, 3, 2, 1, 0]
+    tot = 0.0
+    for (ci, cm, co), l in zip(chans, lv):
+        tot += 2.0 * hs[l] * ws[l] * 9 * (ci * cm + cm * co)
+    return tot + 2.0 * h * w * 64
+
+
+def moving_pattern(t, h, w, device):
+    """Seeded procedural frame (moving blobs + fixed texture) in [0,255] uint8 -> gives the PSNR
+    leg a ground-truth middle frame: frames at t=0,2 in, t=1 is the truth."""
+    ys = torch.arange(h, device=device, dtype=torch.float32)[:, None]
+    xs = torch.arange(w, device=device, dtype=torch.float32)[None, :]
+    img = 96 + 40 * torch.sin(xs / 37.0 + 0.11 * t) * torch.cos(ys / 23.0)
+    for k in range(6):
+        cx = (0.13 * (k + 1) * w + 9.0 * t * (k + 1)) % w
+        cy = (0.29 * (k + 1) * h + 5.0 * t) % h
+        img = img + 90 * torch.exp(-((xs - cx) ** 2 + (ys - cy) ** 2) / (2 * (18.0 + 6 * k) ** 2))
+    return img.clamp(0, 255).to(torch.uint8)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=8)
+    ap.add_argument("--height", type=int, default=1080)
+    ap.add_argument("--width", type=int, default=1920)
+    ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--unfused", action="store_true", help="ablation: separate pool/upsample/head kernels")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N > 1")
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local_rank}"))
+    torch.cuda.set_device(local_rank)
+    dev = torch.device(f"cuda:{local_rank}")
+
+    b, h, w = args.batch, args.height, args.width
+    torch.manual_seed(0)  # same random-init weights on every rank
+    model = P.FrameInterpolationUNet(bilinear=True, precision=args.precision)
+    with torch.no_grad():
+        # He-scaled conv weights and non-trivial BatchNorm statistics so activations stay O(1)
+        # through all 19 layers (torch's default init + identity BN decays towards zero, and
+        # near-zero MFMA operands run at a higher clock than real data: never bench on those).
+        for name, prm in model.named_parameters():
+            if prm.dim() == 4 and prm.shape[-1] == 3:
+                prm.normal_(0, (2.0 / (prm.shape[1] * 9)) ** 0.5)
+            elif prm.dim() == 4:
+                prm.normal_(0, 0.2 / prm.shape[1] ** 0.5)
+            elif name.endswith(".weight"):
+                prm.uniform_(0.6, 1.6)
+            elif name.endswith(".bias"):
+                prm.normal_(0, 0.25 if "double_conv" in name else 0.1)
+        for name, buf in model.named_buffers():
+            if name.endswith("running_mean"):
+                buf.normal_(0, 0.2)
+            elif name.endswith("running_var"):
+                buf.uniform_(0.5, 1.5)
+    model = model.to(dev).eval()
+    model.set_options(unfused=args.unfused)
+
+    gen = torch.Generator(device=dev).manual_seed(1 + rank)
+    f1 = torch.rand(b, 1, h, w, device=dev, generator=gen) * 2 - 1
+    f2 = torch.rand(b, 1, h, w, device=dev, generator=gen) * 2 - 1
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        model(f1, f2)
+    model._ctx.profile_enable(True)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        model(f1, f2)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    nfw, rows = model._ctx.profile_read()
+    model._ctx.profile_enable(False)
+    if dist is not None:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    if rank != 0:
+        if dist is not None:
+            dist.destroy_process_group()
+        return
+
+    fps = world * b * args.steps / elapsed
+    ms_step = elapsed / args.steps * 1e3
+    flops_frame = conv_flops(h, w)
+    es = 2 if args.precision == "bf16" else 4
+
+    # ---- roofline of the dominant kernel (grouped by kernel instantiation) ------------------
+    groups = {}
+    for name, ms, fl in rows:
+        g = groups.setdefault(name, {"ms": 0.0, "flops": 0.0, "launches": 0})
+        g["ms"] += ms; g["flops"] += fl; g["launches"] += 1
+    dom_name, dom = max(groups.items(), key=lambda kv: kv[1]["ms"])
+    peak = PEAK_TFLOPS[args.precision]
+    achieved = dom["flops"] / (dom["ms"] * 1e-3) / 1e12 if dom["ms"] > 0 else 0.0
+    traffic = None
+    pmc = os.path.join(ROOT, "profiles", "pmc_summary.json")
+    if os.path.exists(pmc):
+        try:
+            traffic = json.load(open(pmc)).get(dom_name, {}).get("hbm_bytes_per_launch")
+        except Exception:
+            traffic = None
+    sum_ms = sum(r[1] for r in rows)
+    roofline = {
+        "bound": "mfma", "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s",
+        "frac": round(achieved / peak, 4), "traffic": traffic,
+        "kernel": dom_name, "launches_per_step": dom["launches"],
+        "avg_launch_ms": round(dom["ms"] / dom["launches"], 4),
+        "algorithmic_flops_per_launch": dom["flops"] / dom["launches"],
+        "events_forwards": nfw,
+        "whole_forward": {
+            "tflops": round(fps / world * flops_frame / 1e12, 2),
+            "mfma_frac": round(fps / world * flops_frame / 1e12 / peak, 4),
+            "hbm_algorithmic_gbs": round(fps / world * ELEMS_PER_PIXEL * h * w * es / 1e9, 1),
+            "hbm_frac": round(fps / world * ELEMS_PER_PIXEL * h * w * es / 1e9 / PEAK_HBM_GBS, 4),
+            "sum_stage_ms": round(sum_ms, 3),
+        },
+        "stages": [{"kernel": n, "ms": round(ms, 4), "tflops": round(fl / (ms * 1e-3) / 1e12, 1) if ms > 0 else 0}
+                   for n, ms, fl in rows],
+    }
+
+    result = {
+        "metric": "interpolated frames/sec at 1080p" if (h, w) == (1080, 1920) else f"interpolated frames/sec at {h}x{w}",
+        "value": round(fps, 2), "unit": "frames/s", "n_gpus": world, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": round(ms_step, 3), "higher_is_better": True,
+        "scaling": "weak", "vs_baseline": None, "dtype": args.precision, "data": "synthetic",
+        "config": {"workload": f"batch={b} {w}x{h} synthetic frame pairs per GPU, {args.precision} "
+                               f"MFMA conv path, random-init UNet(2->1, bilinear) weights",
+                   "batch_per_gpu": b, "height": h, "width": w, "fused": not args.unfused,
+                   "parallelism": f"frame-pair shard x{world}, no data-path collective"},
+        "roofline": roofline,
+    }
+
+    # ---- CPU baseline + PSNR leg (N=1 only; bounded: one 1080p pair) --------------------------
+    if world == 1 and not args.no_cpu_baseline:
+        from oracle import unet_oracle as O  # checker / baseline only
+        sd = {k: v.detach().cpu() for k, v in model.state_dict().items()}
+        ncores = os.cpu_count() or 1
+        torch.set_num_threads(ncores)
+        a_u8 = moving_pattern(0, h, w, dev)
+        c_u8 = moving_pattern(2, h, w, dev)
+        gt_u8 = moving_pattern(1, h, w, dev).cpu().numpy()
+        pa = P._native.preprocess_u8(a_u8[None, None])
+        pc = P._native.preprocess_u8(c_u8[None, None])
+        t0 = time.perf_counter()
+        ref = O.unet_forward(sd, pa.cpu(), pc.cpu())
+        cpu_s = time.perf_counter() - t0
+        out = model(pa, pc)
+        ref_u8 = O.postprocess_tensor(ref)
+        hip_u8 = P.postprocess_image(out)
+        model.precision = "fp32"
+        out32 = model(pa, pc)
+        model.precision = args.precision
+        result["cpu_baseline"] = {
+            "value": round(1.0 / cpu_s, 4), "unit": "frames/s", "cores": torch.get_num_threads(),
+            "kind": "port",
+            "sample": f"1 frame pair at {w}x{h}, single run, PyTorch-CPU oracle (oracle/unet_oracle.py), "
+                      f"torch {torch.__version__}, {ncores} host threads",
+        }
+        result["parity"] = {
+            "max_abs_vs_cpu_ref": round(float((out.cpu() - ref).abs().max()), 6),
+            "rel_l2_vs_cpu_ref": round(float((out.cpu() - ref).norm() / ref.norm()), 6),
+            "fp32_path_max_abs_vs_cpu_ref": round(float((out32.cpu() - ref).abs().max()), 8),
+            "psnr_hip_vs_cpu_ref_u8_db": round(O.psnr_u8(ref_u8, hip_u8), 3),
+            "psnr_hip_vs_truth_db": round(O.psnr_u8(gt_u8, hip_u8), 4),
+            "psnr_cpu_vs_truth_db": round(O.psnr_u8(gt_u8, ref_u8), 4),
+            "out_absmax": round(float(ref.abs().max()), 4),
+        }
+        result["parity"]["psnr_delta_db"] = round(
+            abs(result["parity"]["psnr_hip_vs_truth_db"] - result["parity"]["psnr_cpu_vs_truth_db"]), 4)
+    print(json.dumps(result))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

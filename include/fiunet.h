@@ -103,6 +103,16 @@ int fiunet_debug_read_activation(fiunet_ctx* ctx, const void* workspace, int B, 
                                  int precision, int tap, float* dst, int out_dims[3],
                                  void* stream);
 
+/* Measurement hook (bench.py's roofline leg): when enabled, every fiunet_forward records a HIP
+ * event on its stream before the first kernel and after each of the 18 conv stages.
+ * fiunet_profile_read synchronises on them and returns, per stage, the average duration in
+ * ms over the forwards recorded since enable/last read, the stage's algorithmic FLOPs
+ * (2*B*H*W*9*Cin*Cout) and the name of the kernel instantiation that ran it
+ * (names: 18 strings of name_stride bytes).  Not for use under stream capture. */
+int fiunet_profile_enable(fiunet_ctx* ctx, int enable);
+int fiunet_profile_read(fiunet_ctx* ctx, int* n_forwards, float* avg_ms, double* flops,
+                        char* names, int name_stride);
+
 /* Thread-local description of the last non-OK status. */
 const char* fiunet_last_error_string(void);
 

@@ -1,0 +1,84 @@
+"""CPU: the oracles are pinned against golden vectors recorded from the REAL reference model
+(oracle/gen_golden.py imported /root/reference/model/unet.py in the build container)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import unet_oracle as O
+from oracle import c_oracle as C
+
+FULL = ["b1_32x48", "b2_64x64", "b1_17x31", "b1_16x16", "b1_135x240", "b1_256x256"]
+
+
+def _load(golden_dir, name):
+    g = np.load(os.path.join(golden_dir, f"out_{name}.npz"))
+    return torch.from_numpy(g["frame1"]), torch.from_numpy(g["frame2"]), g["out"], int(g["seed"])
+
+
+def test_schema_matches_reference(golden_dir):
+    lines = [l.rstrip("\n").split("\t") for l in open(os.path.join(golden_dir, "state_dict_schema.txt"))]
+    mine = O.state_dict_schema()
+    assert len(lines) == len(mine) == 110
+    for (k, shp, dt), (mk, mshp, mdt) in zip(lines, mine):
+        assert k == mk
+        assert tuple(int(x) for x in shp.split(",") if x) == tuple(mshp)
+        assert dt == str(mdt)
+
+
+def test_seeded_inputs_reproduce(golden_dir):
+    f1, f2, _, seed = _load(golden_dir, "b1_17x31")
+    g1, g2 = O.make_frames(seed, 1, 17, 31)
+    assert torch.equal(f1, g1) and torch.equal(f2, g2)
+
+
+@pytest.mark.parametrize("name", FULL)
+def test_torch_oracle_equals_reference(golden_dir, seeded_sd, name):
+    f1, f2, ref, _ = _load(golden_dir, name)
+    out = O.unet_forward(seeded_sd, f1, f2).numpy()
+    assert out.shape == ref.shape
+    # same aten kernels as the reference run; allow thread-count dependent summation order
+    assert np.abs(out - ref).max() <= 2e-5
+
+
+@pytest.mark.parametrize("name", ["b1_32x48", "b1_17x31", "b1_16x16", "b2_64x64"])
+def test_c_oracle_equals_reference(golden_dir, seeded_sd, name):
+    f1, f2, ref, _ = _load(golden_dir, name)
+    out = C.unet_forward(seeded_sd, f1, f2)
+    assert np.abs(out - ref).max() <= 5e-5  # independent arithmetic (double accumulation)
+
+
+def test_per_layer_fixture(golden_dir, seeded_sd):
+    g = np.load(os.path.join(golden_dir, "layers_b1_32x48.npz"))
+    taps = {}
+    O.unet_forward(seeded_sd, torch.from_numpy(g["frame1"]), torch.from_numpy(g["frame2"]), taps)
+    names = sorted({k.split("|")[0] for k in g.files if "|" in k})
+    assert len(names) == 18 + 4 + 1
+    for n in names:
+        t = taps[n]
+        assert tuple(t.shape) == tuple(g[f"{n}|shape"])
+        got = t.reshape(-1)[torch.from_numpy(g[f"{n}|idx"])].numpy()
+        assert np.abs(got - g[f"{n}|val"]).max() <= 1e-4 * max(1.0, np.abs(g[f"{n}|val"]).max())
+        assert abs(t.double().sum().item() - float(g[f"{n}|sum"])) <= 1e-5 * float(g[f"{n}|abssum"]) + 1e-6
+
+
+def test_1080p_sample_shape_only(golden_dir):
+    g = np.load(os.path.join(golden_dir, "out_b1_1080x1920_sample.npz"))
+    assert g["idx"].shape == g["val"].shape == (4096,)
+    assert int(g["u8_hist"].sum()) == 1080 * 1920
+
+
+def test_postprocess_and_psnr_fixture(golden_dir):
+    g = np.load(os.path.join(golden_dir, "post_b1_64x64.npz"))
+    u8 = O.postprocess_tensor(torch.from_numpy(g["out"]))
+    assert np.array_equal(u8, g["u8"])
+    assert abs(O.psnr_u8(g["gt_u8"], u8) - float(g["psnr"])) < 1e-9
+    # truncation, not rounding (inference.py:61)
+    t = torch.tensor([[[[0.999, -0.999, 0.0, 1.5, -1.5]]]])
+    assert O.postprocess_tensor(t).tolist() == [254, 0, 127, 255, 0]
+
+
+def test_flop_count_matches_survey():
+    assert abs(O.conv_flops(256, 256) / 1e9 - 79.885) < 0.01
+    assert abs(O.conv_flops(1080, 1920) / 1e9 - 2527.04) < 0.05
