@@ -14,7 +14,12 @@
 //   * A "plane" is 64 bytes of channels per pixel (32 bf16 or 16 fp32).  The input tile
 //     (TH+2)x(TW+2) pixels of one plane is staged in LDS ONCE and reused by all 9 taps -- the
 //     shifted windows are just different LDS addresses (base + immediate offset).
-//   * Weights for (plane, ky, kx=0..2) are staged per step: 3*BN rows of 64 B.
+//   * Weights for (plane, ky, kx=0..2) are streamed per step: 3*BN rows of 64 B, by LDS-DMA
+//     (global_load_lds_dwordx4, 1 KiB per wave-instruction, no VGPRs) into a 2-deep ring, one
+//     step ahead of the MFMAs, so the L2 latency of the weight stream hides under the previous
+//     step's 96 MFMAs per wave.  The next plane's input tile is gathered (through registers:
+//     pool / bilinear transforms happen here) at the plane boundary behind one extra barrier;
+//     the co-resident second workgroup of the CU covers that gap.
 //   * Both LDS images are [row][64 B] with the 16-B chunk index XOR-ed by ((row>>2)&1)<<1, which
 //     makes every ds_read_b128 of 16 consecutive rows x 4 chunks conflict-free for any row
 //     alignment (the 16-lane groups of ds_read_b128 are listed in MI355X_MICROARCH.md, LDS).
@@ -126,44 +131,72 @@ __device__ __forceinline__ uint4 chunk_bilerp(const uint4& a, const uint4& b, co
 
 __device__ __forceinline__ uint4 ldg16(const char* p) { return *reinterpret_cast<const uint4*>(p); }
 
-// One 16-byte chunk (plane `plane`, chunk `ch`) of conv-input pixel (b, y, x); zero outside.
+// One 16-byte chunk (plane `plane`, chunk `ch`) of conv-input pixel (b, y, x); zero outside the
+// image (conv padding) and outside the upsampled extent (F.pad).  Branch-free: coordinates are
+// clamped so every load is in bounds and the result is selected afterwards, which keeps the
+// gather in one basic block that the scheduler can overlap with the MFMA stream.
 template <typename T, int MODE>
 __device__ __forceinline__ uint4 gather_chunk(const ConvArgs& a, int b, int y, int x, int plane,
                                               int ch)
 {
     constexpr int PL = Elem<T>::PL;
-    uint4 z = make_uint4(0u, 0u, 0u, 0u);
-    if (y < 0 || y >= a.H || x < 0 || x >= a.W) return z;
+    bool ok = (y >= 0) & (y < a.H) & (x >= 0) & (x < a.W);
+    y = min(max(y, 0), a.H - 1);
+    x = min(max(x, 0), a.W - 1);
     const int p0 = a.C0 / PL;
+    uint4 v;
     if (MODE == SRC_POOL) {
-        const size_t rowb = (size_t)a.s0W * a.C0 * sizeof(T);
-        const char* p = (const char*)a.src0 +
-                        (((size_t)b * a.s0H + 2 * y) * a.s0W + 2 * x) * a.C0 * sizeof(T) +
-                        plane * 64 + ch * 16;
-        const size_t pxb = (size_t)a.C0 * sizeof(T);
-        return chunk_max4<T>(ldg16(p), ldg16(p + pxb), ldg16(p + rowb), ldg16(p + rowb + pxb));
-    }
-    if (MODE == SRC_DIRECT || plane < p0) {
+        const size_t pxb = (size_t)a.C0 * sizeof(T), rowb = (size_t)a.s0W * pxb;
+        const char* p = (const char*)a.src0 + ((size_t)b * a.s0H + 2 * y) * rowb +
+                        (size_t)(2 * x) * pxb + plane * 64 + ch * 16;
+        v = chunk_max4<T>(ldg16(p), ldg16(p + pxb), ldg16(p + rowb), ldg16(p + rowb + pxb));
+    } else if (MODE == SRC_DIRECT || plane < p0) {
         const char* p = (const char*)a.src0 +
                         (((size_t)b * a.H + y) * a.W + x) * a.C0 * sizeof(T) + plane * 64 + ch * 16;
-        return ldg16(p);
+        v = ldg16(p);
+    } else {
+        // CONCAT_UP, upsampled half: channels C0.. come from bilinear x2 of src1, zero-padded.
+        int yu = y - a.padT, xu = x - a.padL;
+        ok = ok & (yu >= 0) & (yu < 2 * a.lowH) & (xu >= 0) & (xu < 2 * a.lowW);
+        yu = min(max(yu, 0), 2 * a.lowH - 1);
+        xu = min(max(xu, 0), 2 * a.lowW - 1);
+        const float fy = a.sy * (float)yu, fx = a.sx * (float)xu;
+        const int y0 = (int)fy, x0 = (int)fx;
+        const int y1 = y0 < a.lowH - 1 ? y0 + 1 : y0, x1 = x0 < a.lowW - 1 ? x0 + 1 : x0;
+        const float ly = fy - (float)y0, lx = fx - (float)x0;
+        const float hy = 1.0f - ly, hx = 1.0f - lx;
+        const char* base = (const char*)a.src1 + (size_t)b * a.lowH * a.lowW * a.C1 * sizeof(T) +
+                           (plane - p0) * 64 + ch * 16;
+        const size_t pxb = (size_t)a.C1 * sizeof(T);
+        const uint4 v00 = ldg16(base + ((size_t)y0 * a.lowW + x0) * pxb);
+        const uint4 v01 = ldg16(base + ((size_t)y0 * a.lowW + x1) * pxb);
+        const uint4 v10 = ldg16(base + ((size_t)y1 * a.lowW + x0) * pxb);
+        const uint4 v11 = ldg16(base + ((size_t)y1 * a.lowW + x1) * pxb);
+        v = chunk_bilerp<T>(v00, v01, v10, v11, hx, lx, hy, ly);
     }
-    // CONCAT_UP, upsampled half: channels C0.. come from bilinear x2 of src1, zero-padded.
-    const int yu = y - a.padT, xu = x - a.padL;
-    if (yu < 0 || yu >= 2 * a.lowH || xu < 0 || xu >= 2 * a.lowW) return z;
-    const float fy = a.sy * (float)yu, fx = a.sx * (float)xu;
-    const int y0 = (int)fy, x0 = (int)fx;
-    const int y1 = y0 < a.lowH - 1 ? y0 + 1 : y0, x1 = x0 < a.lowW - 1 ? x0 + 1 : x0;
-    const float ly = fy - (float)y0, lx = fx - (float)x0;
-    const float hy = 1.0f - ly, hx = 1.0f - lx;
-    const char* base = (const char*)a.src1 + (size_t)b * a.lowH * a.lowW * a.C1 * sizeof(T) +
-                       (plane - p0) * 64 + ch * 16;
-    const size_t pxb = (size_t)a.C1 * sizeof(T);
-    const uint4 v00 = ldg16(base + ((size_t)y0 * a.lowW + x0) * pxb);
-    const uint4 v01 = ldg16(base + ((size_t)y0 * a.lowW + x1) * pxb);
-    const uint4 v10 = ldg16(base + ((size_t)y1 * a.lowW + x0) * pxb);
-    const uint4 v11 = ldg16(base + ((size_t)y1 * a.lowW + x1) * pxb);
-    return chunk_bilerp<T>(v00, v01, v10, v11, hx, lx, hy, ly);
+    return ok ? v : make_uint4(0u, 0u, 0u, 0u);
+}
+
+// LDS-DMA: 16 bytes per lane, global -> LDS, destination = wave-uniform LDS byte address (in M0)
+// + lane*16.  Issued from inline asm ON PURPOSE: hipcc treats the builtin form as an LDS store
+// that may alias every later ds_read and drains it with s_waitcnt vmcnt(0) before the first
+// fragment read of the step, which would serialise the weight stream with the MFMAs.  The asm
+// form is invisible to its wait bookkeeping, so completion is waited for by hand
+// (lds_dma_wait_all) before the barrier that publishes the ring slot.  M0 is saved/restored in
+// the same statement (cdna_hip_programming.md 5.7).
+__device__ __forceinline__ void glds16(const char* gsrc, unsigned lds_wave_base)
+{
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\t"
+                 "global_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(gsrc), "s"(lds_wave_base)
+                 : "memory");
+}
+__device__ __forceinline__ void lds_dma_wait_all() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+__device__ __forceinline__ unsigned lds_addr_of(const char* p)
+{
+    return (unsigned)(uintptr_t)(__attribute__((address_space(3))) const char*)p;
 }
 
 __device__ __forceinline__ int swz(int row) { return ((row >> 2) & 1) << 1; }
@@ -191,8 +224,8 @@ template <int BN, int TH, int TW> struct ConvTile {
     static constexpr int TWP = ((TW + 2 + 7) / 8) * 8;  // in-tile row pitch, multiple of 8 pixels
     static constexpr int THP = TH + 2;
     static constexpr int IN_BYTES = THP * TWP * 64;
-    static constexpr int W_BYTES = 3 * BN * 64;
-    static constexpr int LDS_BYTES = IN_BYTES + W_BYTES;
+    static constexpr int W_BYTES = 3 * BN * 64;          // one (plane, ky) step: 3 taps
+    static constexpr int LDS_BYTES = IN_BYTES + 2 * W_BYTES;  // 2-deep weight ring
 };
 
 template <typename T, int BN, int TH, int TW, int MODE, bool HEAD>
@@ -238,45 +271,67 @@ __global__ __launch_bounds__(256, 2) void conv3x3_mfma_kernel(const ConvArgs a)
         for (int n = 0; n < 8; ++n) acc[m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     // per-lane LDS read offsets (everything else is an immediate)
-    const int a_off = (wc * 64 + l15) * 64 + ((lc ^ swz(l15)) << 4);
+    const int a_off = (wc * 64 + l15) * 64 + ((lc ^ swz(l15)) << 4);  // within a weight ring slot
     int b_off[3];
 #pragma unroll
     for (int kx = 0; kx < 3; ++kx)
         b_off[kx] = (wp * ROWS_W * TWP + kx + l15) * 64 + ((lc ^ swz(kx + l15)) << 4);
 
     const int nplanes = (a.C0 + a.C1) / PL;
+    const int nsteps = nplanes * 3;
     const char* wbase = (const char*)a.wgt + (size_t)ct * BN * 64;
 
-    for (int plane = 0; plane < nplanes; ++plane) {
-        for (int ky = 0; ky < 3; ++ky) {
-            __syncthreads();  // previous step's LDS reads are done
-            if (ky == 0) {
-                for (int i = tid; i < THP * (TW + 2) * 4; i += 256) {
-                    const int pix = i >> 2, ch = i & 3;
-                    const int py = pix / (TW + 2), px = pix - py * (TW + 2);
-                    const uint4 v = gather_chunk<T, MODE>(a, b, y0 - 1 + py, x0 - 1 + px, plane, ch);
-                    const int row = py * TWP + px;
-                    *reinterpret_cast<uint4*>(lds_in + row * 64 + ((ch ^ swz(row)) << 4)) = v;
-                }
-            }
-            {
-                const char* wsrc = wbase + ((size_t)(plane * 9 + ky * 3) * a.Cout) * 64;
+    // weight stream: each wave moves NW 1-KiB pieces (16 LDS rows) per step by LDS-DMA.  The LDS
+    // image is lane-linear, so the XOR swizzle goes on the per-lane SOURCE chunk instead.
+    constexpr int NW = Tile::W_BYTES / 1024 / 4;
+    const unsigned lds_w_addr = lds_addr_of(lds_w);
+    int w_src_off[NW];
 #pragma unroll
-                for (int i = tid; i < 3 * BN * 4; i += 256) {
-                    const int kx = i / (BN * 4), rem = i - kx * (BN * 4);
-                    const int row = rem >> 2, ch = rem & 3;
-                    const uint4 v = ldg16(wsrc + ((size_t)kx * a.Cout + row) * 64 + ch * 16);
-                    const int lrow = kx * BN + row;
-                    *reinterpret_cast<uint4*>(lds_w + lrow * 64 + ((ch ^ swz(lrow)) << 4)) = v;
-                }
-            }
-            __syncthreads();
+    for (int j = 0; j < NW; ++j) {
+        const int lrow = (wave * NW + j) * 16 + (lane >> 2);
+        const int kx = lrow / BN, row = lrow - kx * BN;
+        w_src_off[j] = (kx * a.Cout + row) * 64 + (((lane & 3) ^ swz(lrow)) << 4);
+    }
+    auto issue_w = [&](int step) {
+        const int pl = step / 3, ky = step - pl * 3;
+        const char* wsrc = wbase + ((size_t)(pl * 9 + ky * 3) * a.Cout) * 64;
+        const unsigned dst = __builtin_amdgcn_readfirstlane(
+            lds_w_addr + (unsigned)((step & 1) * Tile::W_BYTES + wave * NW * 1024));
+#pragma unroll
+        for (int j = 0; j < NW; ++j) glds16(wsrc + w_src_off[j], dst + j * 1024);
+    };
+
+    // input-tile gather (global -> registers -> swizzled LDS image), one plane at a time
+    constexpr int NCH = THP * (TW + 2) * 4;
+    auto gather_plane = [&](int plane) {
+        for (int i = tid; i < NCH; i += 256) {
+            const int pix = i >> 2, ch = i & 3;
+            const int py = pix / (TW + 2), px = pix - py * (TW + 2);
+            const uint4 v = gather_chunk<T, MODE>(a, b, y0 - 1 + py, x0 - 1 + px, plane, ch);
+            const int row = py * TWP + px;
+            *reinterpret_cast<uint4*>(lds_in + row * 64 + ((ch ^ swz(row)) << 4)) = v;
+        }
+    };
+
+    issue_w(0);
+    gather_plane(0);
+    lds_dma_wait_all();
+    __syncthreads();
+
+    int step = 0;
+    for (int plane = 0; plane < nplanes; ++plane) {
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky, ++step) {
+            // W(step) and the in-tile of `plane` are resident.  Stream W(step+1) into the other
+            // ring slot (its last readers passed the barrier that ended step-1).
+            if (step + 1 < nsteps) issue_w(step + 1);
+            const char* wcur = lds_w + (step & 1) * Tile::W_BYTES + a_off;
 #pragma unroll
             for (int kx = 0; kx < 3; ++kx) {
                 uint4 wa[4], xb[8];
 #pragma unroll
                 for (int m = 0; m < 4; ++m)
-                    wa[m] = *reinterpret_cast<const uint4*>(lds_w + a_off + (kx * BN + m * 16) * 64);
+                    wa[m] = *reinterpret_cast<const uint4*>(wcur + (kx * BN + m * 16) * 64);
 #pragma unroll
                 for (int n = 0; n < 8; ++n)
                     xb[n] = *reinterpret_cast<const uint4*>(
@@ -286,6 +341,12 @@ __global__ __launch_bounds__(256, 2) void conv3x3_mfma_kernel(const ConvArgs a)
 #pragma unroll
                     for (int n = 0; n < 8; ++n) mma_chunk<T>(acc[m][n], wa[m], xb[n]);
             }
+            if (ky == 2 && plane + 1 < nplanes) {
+                __syncthreads();  // every wave is done reading this plane's in-tile
+                gather_plane(plane + 1);
+            }
+            lds_dma_wait_all();   // this wave's pieces of W(step+1) have landed
+            __syncthreads();      // ... and so have everyone else's; in-tile writes visible
         }
     }
 

@@ -151,6 +151,13 @@ int launch_conv_cfg(ConvArgs a, hipStream_t s)
     a.nct = a.Cout / BN;
     const long long nblk = (long long)a.B * a.tilesX * a.tilesY * a.nct;
     if (nblk <= 0 || nblk > 0x7fffffffLL) return fail(FIUNET_ERR_INVALID_ARG, "conv grid too large");
+    static bool lds_attr_set = false;  // > 64 KiB of dynamic LDS needs the opt-in attribute
+    if (!lds_attr_set) {
+        HIP_TRY(hipFuncSetAttribute(
+            reinterpret_cast<const void*>(&conv3x3_mfma_kernel<T, BN, TH, TW, MODE, HEAD>),
+            hipFuncAttributeMaxDynamicSharedMemorySize, Tile::LDS_BYTES));
+        lds_attr_set = true;
+    }
     hipLaunchKernelGGL((conv3x3_mfma_kernel<T, BN, TH, TW, MODE, HEAD>), dim3((unsigned)nblk),
                        dim3(256), Tile::LDS_BYTES, s, a);
     HIP_TRY(hipGetLastError());
