@@ -54,6 +54,7 @@ struct ConvArgs {
     float sy, sx;        // CONCAT_UP: (low-1)/(2*low-1), align_corners=True scale
     int tilesX, tilesY, nct;
     int relu;
+    const void* zero_page; // >= 64 zero bytes: LDS-DMA source for padding pixels
     const float* head_w; // fused 1x1 head: [head_nc][64]
     const float* head_b; // [head_nc]
     float* head_out;     // fp32 NCHW [B][head_nc][H][W]
@@ -260,7 +261,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_mfma_kernel(const ConvArgs a)
     const int y0 = ty * TH, x0 = tx * TW;
 
     const int tid = threadIdx.x;
-    const int lane = tid & 63, wave = tid >> 6;
+    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l15 = lane & 15, lc = lane >> 4;
     const int wc = wave % WAVES_C, wp = wave / WAVES_C;
 
@@ -292,7 +293,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_mfma_kernel(const ConvArgs a)
         const int kx = lrow / BN, row = lrow - kx * BN;
         w_src_off[j] = (kx * a.Cout + row) * 64 + (((lane & 3) ^ swz(lrow)) << 4);
     }
-    auto issue_w = [&](int step) {
+    auto issue_w = [&](int step) __attribute__((always_inline)) {
         const int pl = step / 3, ky = step - pl * 3;
         const char* wsrc = wbase + ((size_t)(pl * 9 + ky * 3) * a.Cout) * 64;
         const unsigned dst = __builtin_amdgcn_readfirstlane(
@@ -301,16 +302,73 @@ __global__ __launch_bounds__(256, 2) void conv3x3_mfma_kernel(const ConvArgs a)
         for (int j = 0; j < NW; ++j) glds16(wsrc + w_src_off[j], dst + j * 1024);
     };
 
-    // input-tile gather (global -> registers -> swizzled LDS image), one plane at a time
-    constexpr int NCH = THP * (TW + 2) * 4;
-    auto gather_plane = [&](int plane) {
-        for (int i = tid; i < NCH; i += 256) {
-            const int pix = i >> 2, ch = i & 3;
-            const int py = pix / (TW + 2), px = pix - py * (TW + 2);
-            const uint4 v = gather_chunk<T, MODE>(a, b, y0 - 1 + py, x0 - 1 + px, plane, ch);
-            const int row = py * TWP + px;
-            *reinterpret_cast<uint4*>(lds_in + row * 64 + ((ch ^ swz(row)) << 4)) = v;
+    // ---- input-tile gather, one plane at a time ------------------------------------------------
+    // (a) planes read straight from an NHWC tensor (all DIRECT planes, the skip half of a
+    //     concat) go by LDS-DMA: piece j = 16 consecutive LDS rows (pixels) x 64 B, lane ->
+    //     (row, chunk) with the swizzle applied to the per-lane SOURCE chunk; pixels outside the
+    //     image and the row-pitch padding read a 64-byte zero page.  No VGPRs, one memory round
+    //     trip per plane.
+    // (b) pooled / bilinearly upsampled planes need arithmetic, so they go through registers,
+    //     GB chunks (4 loads each) in flight at a time.
+    constexpr int NPIECE = THP * TWP / 16;
+    static_assert(THP * TWP % 16 == 0, "in-tile must be a whole number of 1-KiB pieces");
+    const unsigned lds_in_addr = lds_addr_of(lds_in);
+    const int aH = a.H, aW = a.W;
+    const char* const dma_src = (const char*)a.src0 + (size_t)b * a.H * a.W * a.C0 * sizeof(T);
+    const unsigned dma_px_bytes = a.C0 * sizeof(T);
+    const char* const zero_page = (const char*)a.zero_page;
+    auto gather_plane_dma = [&](int plane) __attribute__((always_inline)) {
+        int opq = 0;  // opaque zero: keeps the per-piece address math out of the K loop's
+        asm volatile("" : "+s"(opq));  // invariant-hoisting (it would pin ~2 VGPRs per piece)
+#pragma unroll 1
+        for (int j = wave; j < NPIECE; j += 4) {
+            {
+                const int row = j * 16 + (lane >> 2) + opq;
+                const int py = row / TWP, px = row - py * TWP;
+                const int y = y0 - 1 + py, x = x0 - 1 + px;
+                const bool ok = (px < TW + 2) & (y >= 0) & (y < aH) & (x >= 0) & (x < aW);
+                // one image is < 4 GiB, so a 32-bit byte offset from the batch base is enough
+                const unsigned off = (unsigned)(y * aW + x) * dma_px_bytes + plane * 64 +
+                                     (((lane & 3) ^ swz(row)) << 4);
+                const char* src = ok ? dma_src + off : zero_page + ((lane & 3) << 4);
+                glds16(src, __builtin_amdgcn_readfirstlane(lds_in_addr + (unsigned)j * 1024u));
+            }
         }
+    };
+    constexpr int NCH = THP * (TW + 2) * 4;
+    constexpr int NG = (NCH + 255) / 256;
+    constexpr int GB = 2;
+    auto gather_plane_regs = [&](int plane) __attribute__((always_inline)) {
+        int opq = 0;
+        asm volatile("" : "+v"(opq));
+        const int tido = tid + opq;
+#pragma unroll
+        for (int k0 = 0; k0 < NG; k0 += GB) {
+            uint4 g[GB];
+#pragma unroll
+            for (int k = 0; k < GB; ++k) {
+                const int i = tido + (k0 + k) * 256;
+                const int pix = i >> 2, ch = i & 3;
+                const int py = pix / (TW + 2), px = pix - py * (TW + 2);
+                if (k0 + k < NG)
+                    g[k] = gather_chunk<T, MODE>(a, b, y0 - 1 + py, x0 - 1 + px, plane, ch);
+            }
+#pragma unroll
+            for (int k = 0; k < GB; ++k) {
+                const int i = tido + (k0 + k) * 256;
+                const int pix = i >> 2, ch = i & 3;
+                const int py = pix / (TW + 2), px = pix - py * (TW + 2);
+                const int row = py * TWP + px;
+                if (k0 + k < NG && i < NCH)
+                    *reinterpret_cast<uint4*>(lds_in + row * 64 + ((ch ^ swz(row)) << 4)) = g[k];
+            }
+        }
+    };
+    auto gather_plane = [&](int plane) __attribute__((always_inline)) {
+        if (MODE == SRC_DIRECT || (MODE == SRC_CONCAT_UP && plane < a.C0 / PL))
+            gather_plane_dma(plane);
+        else
+            gather_plane_regs(plane);
     };
 
     issue_w(0);

@@ -106,6 +106,7 @@ struct fiunet_ctx {
     ConvWeights conv[NCONV];
     float* head_w = nullptr;  // [cf][64]
     float* head_b = nullptr;  // [cf]
+    void* zero_page = nullptr;  // 256 zero bytes (LDS-DMA source for conv padding)
     std::vector<void*> owned;
     // per-layer HIP-event profiling (fiunet_profile_*): NCONV+1 events per recorded forward
     bool profiling = false;
@@ -253,6 +254,7 @@ int forward_impl(fiunet_ctx* ctx, const float* f1, const float* f2, float* out, 
         a.wgt = bf16 ? cw.w_bf16 : cw.w_f32;
         a.scale = cw.scale; a.shift = cw.shift;
         a.relu = 1;
+        a.zero_page = ctx->zero_page;
         a.dst = act(i);
         int mode = kMode[i];
         a.src0 = act(kSrc0[i]);
@@ -430,6 +432,8 @@ int fiunet_load_weights(fiunet_ctx* ctx, int n, const char* const* names,
         if ((rc = get("unet.outc.conv.bias", ctx->cf, &bi))) return rc;
         if ((rc = dev_upload(ctx, w, (size_t)ctx->cf * 64 * 4, (void**)&ctx->head_w))) return rc;
         if ((rc = dev_upload(ctx, bi, (size_t)ctx->cf * 4, (void**)&ctx->head_b))) return rc;
+        const std::vector<char> zeros(256, 0);
+        if ((rc = dev_upload(ctx, zeros.data(), zeros.size(), &ctx->zero_page))) return rc;
     }
     ctx->loaded = true;
     return FIUNET_OK;
