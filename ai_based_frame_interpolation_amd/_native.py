@@ -18,7 +18,7 @@ import subprocess
 import torch  # noqa: F401  (must precede CDLL: see module docstring)
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_PKG, "libfiunet_hip.so")
+LIB_PATH = os.environ.get("FIUNET_LIB") or os.path.join(_PKG, "libfiunet_hip.so")  # FIUNET_LIB: A/B builds
 CSRC = os.path.join(_PKG, "csrc")
 
 FP32, BF16 = 0, 1

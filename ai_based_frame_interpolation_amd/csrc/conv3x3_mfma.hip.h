@@ -32,6 +32,10 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#ifndef FIUNET_GB
+#define FIUNET_GB 2
+#endif
+
 namespace fiunet {
 
 typedef __attribute__((ext_vector_type(4))) float f32x4;
@@ -103,10 +107,35 @@ template <> __device__ __forceinline__ uint4 chunk_pack<__bf16>(const float* f)
                       pack_bf16x2(f[6], f[7]));
 }
 
+typedef __attribute__((ext_vector_type(2))) short s16x2;
+__device__ __forceinline__ unsigned pk_max_i16(unsigned a, unsigned b)
+{
+    const s16x2 x = __builtin_bit_cast(s16x2, a), y = __builtin_bit_cast(s16x2, b);
+    return __builtin_bit_cast(unsigned, __builtin_elementwise_max(x, y));  // v_pk_max_i16
+}
+
 template <typename T>
 __device__ __forceinline__ uint4 chunk_max4(const uint4& a, const uint4& b, const uint4& c,
-                                            const uint4& d)
+                                            const uint4& d);
+
+// bf16 max-pool of NON-NEGATIVE values (every pooled tensor in this network is a ReLU output):
+// for x >= 0 the bf16 order equals the signed 16-bit integer order of the bit patterns, and a
+// stray -0.0 (0x8000 = INT16_MIN) loses against everything, so a packed integer max is exact.
+template <>
+__device__ __forceinline__ uint4 chunk_max4<__bf16>(const uint4& a, const uint4& b, const uint4& c,
+                                                    const uint4& d)
 {
+    return make_uint4(pk_max_i16(pk_max_i16(a.x, b.x), pk_max_i16(c.x, d.x)),
+                      pk_max_i16(pk_max_i16(a.y, b.y), pk_max_i16(c.y, d.y)),
+                      pk_max_i16(pk_max_i16(a.z, b.z), pk_max_i16(c.z, d.z)),
+                      pk_max_i16(pk_max_i16(a.w, b.w), pk_max_i16(c.w, d.w)));
+}
+
+template <>
+__device__ __forceinline__ uint4 chunk_max4<float>(const uint4& a, const uint4& b, const uint4& c,
+                                                   const uint4& d)
+{
+    using T = float;
     constexpr int NE = Elem<T>::NE;
     float fa[NE], fb[NE], fc[NE], fd[NE], r[NE];
     chunk_unpack<T>(a, fa); chunk_unpack<T>(b, fb); chunk_unpack<T>(c, fc); chunk_unpack<T>(d, fd);
@@ -124,9 +153,14 @@ __device__ __forceinline__ uint4 chunk_bilerp(const uint4& a, const uint4& b, co
     constexpr int NE = Elem<T>::NE;
     float fa[NE], fb[NE], fc[NE], fd[NE], r[NE];
     chunk_unpack<T>(a, fa); chunk_unpack<T>(b, fb); chunk_unpack<T>(c, fc); chunk_unpack<T>(d, fd);
+    // explicit fma pattern: the same bits in every kernel this is inlined into (hipcc's default
+    // fp-contract=fast would otherwise pick a different contraction per context)
 #pragma unroll
-    for (int i = 0; i < NE; ++i)
-        r[i] = hy * (hx * fa[i] + lx * fb[i]) + ly * (hx * fc[i] + lx * fd[i]);
+    for (int i = 0; i < NE; ++i) {
+        const float top = fmaf(lx, fb[i], __fmul_rn(hx, fa[i]));
+        const float bot = fmaf(lx, fd[i], __fmul_rn(hx, fc[i]));
+        r[i] = fmaf(ly, bot, __fmul_rn(hy, top));
+    }
     return chunk_pack<T>(r);
 }
 
@@ -161,11 +195,12 @@ __device__ __forceinline__ uint4 gather_chunk(const ConvArgs& a, int b, int y, i
         ok = ok & (yu >= 0) & (yu < 2 * a.lowH) & (xu >= 0) & (xu < 2 * a.lowW);
         yu = min(max(yu, 0), 2 * a.lowH - 1);
         xu = min(max(xu, 0), 2 * a.lowW - 1);
-        const float fy = a.sy * (float)yu, fx = a.sx * (float)xu;
+        // no contraction here either: fy must be the ROUNDED product, as in aten
+        const float fy = __fmul_rn(a.sy, (float)yu), fx = __fmul_rn(a.sx, (float)xu);
         const int y0 = (int)fy, x0 = (int)fx;
         const int y1 = y0 < a.lowH - 1 ? y0 + 1 : y0, x1 = x0 < a.lowW - 1 ? x0 + 1 : x0;
-        const float ly = fy - (float)y0, lx = fx - (float)x0;
-        const float hy = 1.0f - ly, hx = 1.0f - lx;
+        const float ly = __fsub_rn(fy, (float)y0), lx = __fsub_rn(fx, (float)x0);
+        const float hy = __fsub_rn(1.0f, ly), hx = __fsub_rn(1.0f, lx);
         const char* base = (const char*)a.src1 + (size_t)b * a.lowH * a.lowW * a.C1 * sizeof(T) +
                            (plane - p0) * 64 + ch * 16;
         const size_t pxb = (size_t)a.C1 * sizeof(T);
@@ -337,7 +372,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_mfma_kernel(const ConvArgs a)
     };
     constexpr int NCH = THP * (TW + 2) * 4;
     constexpr int NG = (NCH + 255) / 256;
-    constexpr int GB = 2;
+    constexpr int GB = FIUNET_GB;  // chunks (x4 loads) in flight per thread on the register path
     auto gather_plane_regs = [&](int plane) __attribute__((always_inline)) {
         int opq = 0;
         asm volatile("" : "+v"(opq));

@@ -229,7 +229,8 @@ int forward_impl(fiunet_ctx* ctx, const float* f1, const float* f2, float* out, 
     // conv 0: fp32 stem (unet.py:72, first conv of inc)
     {
         const ConvWeights& cw = ctx->conv[0];
-        dim3 grid((W + 255) / 256, H, B);
+        const long long ntiles = (long long)B * H * ((W + 15) / 16);
+        dim3 grid((unsigned)std::min<long long>((ntiles + 3) / 4, 256 * 64));
         if (ctx->cf == 1)
             hipLaunchKernelGGL((conv3x3_first_kernel<T, 1>), grid, dim3(256), 0, s, f1, f2,
                                (const float*)cw.w_f32, cw.scale, cw.shift, act(0), B, H, W);

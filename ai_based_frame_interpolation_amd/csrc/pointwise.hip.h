@@ -1,7 +1,7 @@
 // pointwise.hip.h -- the HBM-bound kernels of the UNet forward, gfx950 only.
 //
-//   conv3x3_first_kernel   : the Cin = 2*cf (2 or 6) stem conv + BN + ReLU, fp32 VALU arithmetic
-//                            (K = 18 is too thin for MFMA and the layer is write-bound)
+//   conv3x3_first_kernel   : the Cin = 2*cf (2 or 6) stem conv + BN + ReLU on the exact-fp32 MFMA
+//                            (K = 18/54 padded to 20/56; the layer is write-bound)
 //                            -- /root/reference/model/unet.py:72 (inc.double_conv.0..2)
 //   maxpool2_kernel        : MaxPool2d(2), NHWC (ablation path; normally fused into the conv gather)
 //                            -- unet.py:28
@@ -16,50 +16,78 @@
 
 namespace fiunet {
 
-// One thread = one output pixel x 64 couts.  Weights [9][2*CF][64] are wave-uniform, so the
-// compiler keeps them on the scalar path (s_load + SGPR operand of v_fma).
+// Stem conv on the fp32 matrix cores (exact fp32: v_mfma_f32_16x16x4_f32 is a k-ordered fmaf
+// chain).  One wave = one 16-pixel row segment x 64 couts per iteration:
+//   A (weights)  [16 couts][4 k]  kept in registers for the whole kernel (4 cout tiles x KG k-groups)
+//   B (patches)  [4 k][16 pixels] one global load per lane per k-group, k = (tap, input channel)
+// The A rows are permuted so that lane (pixel, q) ends up with couts 16q..16q+15: its epilogue
+// is 32 (bf16) / 64 (fp32) contiguous bytes and the 4 lanes of a pixel cover its whole 64-channel
+// NHWC record.  K = 18 (gray) or 54 (RGB) is zero-padded to a multiple of 4.
 template <typename T, int CF>
 __global__ __launch_bounds__(256) void conv3x3_first_kernel(
     const float* __restrict__ f1, const float* __restrict__ f2, const float* __restrict__ w,
     const float* __restrict__ scale, const float* __restrict__ shift, T* __restrict__ dst, int B,
     int H, int W)
 {
-    const int x = blockIdx.x * 256 + threadIdx.x;
-    const int y = blockIdx.y, b = blockIdx.z;
-    if (x >= W) return;
-    float in[9][2 * CF];
+    constexpr int K = 9 * 2 * CF, KG = (K + 3) / 4;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int l15 = lane & 15, lc = lane >> 4;
+    float a[4][KG];
+    int koff[KG];  // per k-group: this lane's tap/channel, packed as (dy+1) | (dx+1)<<2 | ch<<4, or -1
 #pragma unroll
-    for (int ky = 0; ky < 3; ++ky)
+    for (int g = 0; g < KG; ++g) {
+        const int k = 4 * g + lc;
+        const int tap = k / (2 * CF), ci = k - tap * (2 * CF);
+        koff[g] = k < K ? ((tap / 3) | ((tap % 3) << 2) | (ci << 4)) : -1;
 #pragma unroll
-        for (int kx = 0; kx < 3; ++kx) {
-            const int yy = y + ky - 1, xx = x + kx - 1;
-            const bool ok = yy >= 0 && yy < H && xx >= 0 && xx < W;
-#pragma unroll
-            for (int c = 0; c < CF; ++c) {
-                const size_t o = (((size_t)b * CF + c) * H + yy) * W + xx;
-                in[ky * 3 + kx][c] = ok ? f1[o] : 0.f;        // cat([frame1, frame2], dim=1):
-                in[ky * 3 + kx][CF + c] = ok ? f2[o] : 0.f;   // unet.py:109
-            }
+        for (int ct = 0; ct < 4; ++ct) {
+            const int cout = (l15 >> 2) * 16 + ct * 4 + (l15 & 3);
+            a[ct][g] = k < K ? w[k * 64 + cout] : 0.f;
         }
-    T* o = dst + (((size_t)b * H + y) * W + x) * 64;
+    }
+    float sc[16], sh[16];
 #pragma unroll
-    for (int cb = 0; cb < 64; cb += 16) {
-        float acc[16];
+    for (int c = 0; c < 16; ++c) { sc[c] = scale[lc * 16 + c]; sh[c] = shift[lc * 16 + c]; }
+
+    const int tilesX = (W + 15) / 16;
+    const long long ntiles = (long long)B * H * tilesX;
+    const size_t plane = (size_t)H * W;
+    for (long long t = (long long)blockIdx.x * 4 + wave; t < ntiles; t += (long long)gridDim.x * 4) {
+        const int xt = (int)(t % tilesX);
+        const long long r = t / tilesX;
+        const int y = (int)(r % H), b = (int)(r / H);
+        const int x = xt * 16 + l15;
+        float v[KG];
 #pragma unroll
-        for (int c = 0; c < 16; ++c) acc[c] = 0.f;
+        for (int g = 0; g < KG; ++g) {
+            const int ko = koff[g];
+            const int yy = y + (ko & 3) - 1, xx = x + ((ko >> 2) & 3) - 1, ci = ko >> 4;
+            const bool ok = ko >= 0 && yy >= 0 && yy < H && xx >= 0 && xx < W;
+            // channel order of cat([frame1, frame2], dim=1)  (unet.py:109)
+            const float* src = ci < CF ? f1 : f2;
+            const int cc = ci < CF ? ci : ci - CF;
+            v[g] = ok ? src[((size_t)b * CF + cc) * plane + (size_t)yy * W + xx] : 0.f;
+        }
+        f32x4 acc[4];
 #pragma unroll
-        for (int k = 0; k < 9; ++k)
+        for (int ct = 0; ct < 4; ++ct) acc[ct] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int ci = 0; ci < 2 * CF; ++ci)
+        for (int g = 0; g < KG; ++g)
 #pragma unroll
-                for (int c = 0; c < 16; ++c)
-                    acc[c] = fmaf(in[k][ci], w[(k * 2 * CF + ci) * 64 + cb + c], acc[c]);
+            for (int ct = 0; ct < 4; ++ct)
+                acc[ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[ct][g], v[g], acc[ct], 0, 0, 0);
+        float o[16];
 #pragma unroll
-        for (int c = 0; c < 16; ++c) acc[c] = fmaxf(acc[c] * scale[cb + c] + shift[cb + c], 0.f);
-        constexpr int NE = Elem<T>::NE;
+        for (int ct = 0; ct < 4; ++ct)
 #pragma unroll
-        for (int c = 0; c < 16; c += NE)
-            *reinterpret_cast<uint4*>(o + cb + c) = chunk_pack<T>(acc + c);
+            for (int j = 0; j < 4; ++j)
+                o[ct * 4 + j] = fmaxf(acc[ct][j] * sc[ct * 4 + j] + sh[ct * 4 + j], 0.f);
+        if (x < W) {
+            T* op = dst + (((size_t)b * H + y) * W + x) * 64 + lc * 16;
+            constexpr int NE = Elem<T>::NE;
+#pragma unroll
+            for (int c = 0; c < 16; c += NE) *reinterpret_cast<uint4*>(op + c) = chunk_pack<T>(o + c);
+        }
     }
 }
 
