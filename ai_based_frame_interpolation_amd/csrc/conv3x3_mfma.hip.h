@@ -473,10 +473,10 @@ __global__ __launch_bounds__(256, 2) void conv3x3_mfma_kernel(const ConvArgs a)
 #pragma unroll
         for (int m = 0; m < 4; ++m) {
             float v[4];
-            v[0] = acc[m][n][0] * sc[m].x + sh[m].x;
-            v[1] = acc[m][n][1] * sc[m].y + sh[m].y;
-            v[2] = acc[m][n][2] * sc[m].z + sh[m].z;
-            v[3] = acc[m][n][3] * sc[m].w + sh[m].w;
+            v[0] = fmaf(acc[m][n][0], sc[m].x, sh[m].x);
+            v[1] = fmaf(acc[m][n][1], sc[m].y, sh[m].y);
+            v[2] = fmaf(acc[m][n][2], sc[m].z, sh[m].z);
+            v[3] = fmaf(acc[m][n][3], sc[m].w, sh[m].w);
             if (a.relu) {
 #pragma unroll
                 for (int j = 0; j < 4; ++j) v[j] = fmaxf(v[j], 0.f);

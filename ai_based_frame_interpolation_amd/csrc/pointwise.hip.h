@@ -52,12 +52,11 @@ __global__ __launch_bounds__(256) void conv3x3_first_kernel(
     const int tilesX = (W + 15) / 16;
     const long long ntiles = (long long)B * H * tilesX;
     const size_t plane = (size_t)H * W;
-    for (long long t = (long long)blockIdx.x * 4 + wave; t < ntiles; t += (long long)gridDim.x * 4) {
+    auto load_tile = [&](long long t, float* v) __attribute__((always_inline)) {
         const int xt = (int)(t % tilesX);
         const long long r = t / tilesX;
         const int y = (int)(r % H), b = (int)(r / H);
         const int x = xt * 16 + l15;
-        float v[KG];
 #pragma unroll
         for (int g = 0; g < KG; ++g) {
             const int ko = koff[g];
@@ -68,6 +67,20 @@ __global__ __launch_bounds__(256) void conv3x3_first_kernel(
             const int cc = ci < CF ? ci : ci - CF;
             v[g] = ok ? src[((size_t)b * CF + cc) * plane + (size_t)yy * W + xx] : 0.f;
         }
+    };
+    const long long tstep = (long long)gridDim.x * 4;
+    long long t = (long long)blockIdx.x * 4 + wave;
+    float vn[KG];
+    if (t < ntiles) load_tile(t, vn);
+    for (; t < ntiles; t += tstep) {
+        float v[KG];
+#pragma unroll
+        for (int g = 0; g < KG; ++g) v[g] = vn[g];
+        if (t + tstep < ntiles) load_tile(t + tstep, vn);  // prefetch: hides the load latency
+        const int xt = (int)(t % tilesX);
+        const long long r = t / tilesX;
+        const int y = (int)(r % H), b = (int)(r / H);
+        const int x = xt * 16 + l15;
         f32x4 acc[4];
 #pragma unroll
         for (int ct = 0; ct < 4; ++ct) acc[ct] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -81,7 +94,7 @@ __global__ __launch_bounds__(256) void conv3x3_first_kernel(
         for (int ct = 0; ct < 4; ++ct)
 #pragma unroll
             for (int j = 0; j < 4; ++j)
-                o[ct * 4 + j] = fmaxf(acc[ct][j] * sc[ct * 4 + j] + sh[ct * 4 + j], 0.f);
+                o[ct * 4 + j] = fmaxf(fmaf(acc[ct][j], sc[ct * 4 + j], sh[ct * 4 + j]), 0.f);
         if (x < W) {
             T* op = dst + (((size_t)b * H + y) * W + x) * 64 + lc * 16;
             constexpr int NE = Elem<T>::NE;
