@@ -9,6 +9,7 @@
 // gfx950 only; no CPU fallback: every entry point either launches HIP kernels or returns an error.
 #include "../../include/fiunet.h"
 #include "pointwise.hip.h"
+#include "conv3x3_pers.hip.h"
 
 #include <algorithm>
 #include <cmath>
@@ -191,6 +192,61 @@ int launch_conv_mode(const ConvArgs& a, bool head, hipStream_t s)
                 : launch_conv_cfg<T, 128, 16, 16, MODE, false>(a, s);
 }
 
+int g_num_cus = 0;  // multiProcessorCount of the context's device (set in fiunet_create)
+
+template <typename T, int BN, int MODE, bool HEAD>
+int launch_pers_cfg(ConvArgs a, hipStream_t s)
+{
+    using Tile = PersTile<BN>;
+    a.tilesX = (a.W + Tile::TW - 1) / Tile::TW;
+    a.tilesY = (a.H + Tile::TH - 1) / Tile::TH;
+    a.nct = a.Cout / BN;
+    const long long total = (long long)a.B * a.tilesX * a.tilesY * a.nct;
+    if (total <= 0 || total > 0x7fffffffLL) return fail(FIUNET_ERR_INVALID_ARG, "conv grid too large");
+    if (g_name_out) {
+        char buf[128];
+        std::snprintf(buf, sizeof buf, "conv3x3_pers_kernel<%s,%d,%d,%d>",
+                      sizeof(T) == 2 ? "bf16" : "f32", BN, MODE, (int)HEAD);
+        *g_name_out = buf;
+    }
+    static bool lds_attr_set = false;
+    if (!lds_attr_set) {
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_pers_kernel<T, BN, MODE, HEAD>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, Tile::LDS_BYTES));
+        lds_attr_set = true;
+    }
+    const int grid = std::max(8, (g_num_cus / 8) * 8);  // one persistent workgroup per CU
+    hipLaunchKernelGGL((conv3x3_pers_kernel<T, BN, MODE, HEAD>), dim3(grid), dim3(512),
+                       Tile::LDS_BYTES, s, a);
+    HIP_TRY(hipGetLastError());
+    return FIUNET_OK;
+}
+
+template <typename T, int MODE> int launch_pers_mode(const ConvArgs& a, bool head, hipStream_t s)
+{
+    if (a.Cout == 64) {
+        if constexpr (MODE == SRC_DIRECT) {
+            if (head) return launch_pers_cfg<T, 64, MODE, true>(a, s);
+        }
+        if constexpr (MODE != SRC_POOL) return launch_pers_cfg<T, 64, MODE, false>(a, s);
+        return fail(FIUNET_ERR_INVALID_ARG, "no pooled conv variant with 64 couts");
+    }
+    if (a.Cout % 128 != 0) return fail(FIUNET_ERR_INVALID_ARG, "Cout must be 64 or k*128");
+    return launch_pers_cfg<T, 128, MODE, false>(a, s);
+}
+
+template <typename T> int launch_pers(const ConvArgs& a, int mode, bool head, hipStream_t s)
+{
+    constexpr int PL = Elem<T>::PL;
+    if (a.C0 % PL || a.C1 % PL) return fail(FIUNET_ERR_INVALID_ARG, "channels not a plane multiple");
+    switch (mode) {
+    case SRC_DIRECT: return launch_pers_mode<T, SRC_DIRECT>(a, head, s);
+    case SRC_POOL: return launch_pers_mode<T, SRC_POOL>(a, head, s);
+    case SRC_CONCAT_UP: return launch_pers_mode<T, SRC_CONCAT_UP>(a, head, s);
+    }
+    return fail(FIUNET_ERR_INVALID_ARG, "bad gather mode");
+}
+
 template <typename T> int launch_conv(const ConvArgs& a, int mode, bool head, hipStream_t s)
 {
     constexpr int PL = Elem<T>::PL;
@@ -292,7 +348,8 @@ int forward_impl(fiunet_ctx* ctx, const float* f1, const float* f2, float* out, 
             if (!(ctx->flags & FIUNET_OPT_KEEP_ALL)) a.dst = nullptr;
         }
         g_name_out = ev ? &ctx->layer_name[i] : nullptr;
-        const int rc = launch_conv<T>(a, mode, head, s);
+        const int rc = (ctx->flags & FIUNET_OPT_CLASSIC) ? launch_conv<T>(a, mode, head, s)
+                                                         : launch_pers<T>(a, mode, head, s);
         g_name_out = nullptr;
         if (rc != FIUNET_OK) return rc;
         if (ev) {
@@ -335,6 +392,9 @@ int fiunet_create(fiunet_ctx** out_ctx, int device_id, int frame_channels, int b
     if (!c) return fail(FIUNET_ERR_INVALID_ARG, "out of host memory");
     c->device = device_id;
     c->cf = frame_channels;
+    hipDeviceProp_t prop;
+    HIP_TRY(hipGetDeviceProperties(&prop, device_id));
+    g_num_cus = prop.multiProcessorCount;
     *out_ctx = c;
     return FIUNET_OK;
 }
