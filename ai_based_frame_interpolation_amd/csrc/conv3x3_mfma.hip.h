@@ -41,18 +41,18 @@ namespace fiunet {
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 
-enum SrcMode { SRC_DIRECT = 0, SRC_POOL = 1, SRC_CONCAT_UP = 2 };
+enum SrcMode { SRC_DIRECT = 0, SRC_POOL = 1 /* host-side tag only */, SRC_CONCAT_UP = 2 };
 
 struct ConvArgs {
-    const void* src0;    // DIRECT/CONCAT_UP: [B][H][W][C0]; POOL: [B][s0H][s0W][C0] (pre-pool)
+    const void* src0;    // [B][H][W][C0]
     const void* src1;    // CONCAT_UP: low-res [B][lowH][lowW][C1], bilinearly upsampled on the fly
     const void* wgt;     // [Cin/PL][9][Cout][PL]  (plane-major, then tap, cout, channel-in-plane)
     const float* scale;  // [Cout]  gamma / sqrt(var + eps)
     const float* shift;  // [Cout]  beta - mean * scale
     void* dst;           // [B][H][W][Cout] or nullptr (fused head only)
+    void* pool_dst;      // EPI_POOL: [B][H/2][W/2][Cout], MaxPool2d(2) of dst
     int B, H, W;         // conv input == output spatial size
     int C0, C1, Cout;
-    int s0H, s0W;        // POOL: spatial size of src0
     int lowH, lowW;      // CONCAT_UP: spatial size of src1
     int padT, padL;      // CONCAT_UP: F.pad top/left (unet.py:52-53)
     float sy, sx;        // CONCAT_UP: (low-1)/(2*low-1), align_corners=True scale
@@ -166,10 +166,34 @@ __device__ __forceinline__ uint4 chunk_bilerp(const uint4& a, const uint4& b, co
 
 __device__ __forceinline__ uint4 ldg16(const char* p) { return *reinterpret_cast<const uint4*>(p); }
 
-// One 16-byte chunk (plane `plane`, chunk `ch`) of conv-input pixel (b, y, x); zero outside the
-// image (conv padding) and outside the upsampled extent (F.pad).  Branch-free: coordinates are
-// clamped so every load is in bounds and the result is selected afterwards, which keeps the
-// gather in one basic block that the scheduler can overlap with the MFMA stream.
+// Bilinear x2 (align_corners=True) source coordinates and weights of one upsampled+padded pixel
+// (unet.py:40,49-53), shared by every kernel that upsamples so they agree bit for bit.
+struct UpCoord {
+    int y0, y1, x0, x1;
+    float hy, ly, hx, lx;
+    bool ok;
+};
+__device__ __forceinline__ UpCoord up_coord(const ConvArgs& a, int y, int x)
+{
+    UpCoord u;
+    int yu = y - a.padT, xu = x - a.padL;
+    u.ok = (yu >= 0) & (yu < 2 * a.lowH) & (xu >= 0) & (xu < 2 * a.lowW);
+    yu = min(max(yu, 0), 2 * a.lowH - 1);
+    xu = min(max(xu, 0), 2 * a.lowW - 1);
+    // fy is the ROUNDED product, as in aten (the library is built with -ffp-contract=off)
+    const float fy = a.sy * (float)yu, fx = a.sx * (float)xu;
+    u.y0 = (int)fy; u.x0 = (int)fx;
+    u.y1 = u.y0 < a.lowH - 1 ? u.y0 + 1 : u.y0;
+    u.x1 = u.x0 < a.lowW - 1 ? u.x0 + 1 : u.x0;
+    u.ly = fy - (float)u.y0; u.lx = fx - (float)u.x0;
+    u.hy = 1.0f - u.ly; u.hx = 1.0f - u.lx;
+    return u;
+}
+
+// One 16-byte chunk (plane `plane`, chunk `ch`) of conv-input pixel (b, y, x) straight from
+// global memory; zero outside the image (conv padding) and outside the upsampled extent (F.pad).
+// Used by the standalone (ablation) upsample+concat kernel; the fused conv computes the same
+// values from an LDS-staged low-res tile.
 template <typename T, int MODE>
 __device__ __forceinline__ uint4 gather_chunk(const ConvArgs& a, int b, int y, int x, int plane,
                                               int ch)
@@ -180,35 +204,21 @@ __device__ __forceinline__ uint4 gather_chunk(const ConvArgs& a, int b, int y, i
     x = min(max(x, 0), a.W - 1);
     const int p0 = a.C0 / PL;
     uint4 v;
-    if (MODE == SRC_POOL) {
-        const size_t pxb = (size_t)a.C0 * sizeof(T), rowb = (size_t)a.s0W * pxb;
-        const char* p = (const char*)a.src0 + ((size_t)b * a.s0H + 2 * y) * rowb +
-                        (size_t)(2 * x) * pxb + plane * 64 + ch * 16;
-        v = chunk_max4<T>(ldg16(p), ldg16(p + pxb), ldg16(p + rowb), ldg16(p + rowb + pxb));
-    } else if (MODE == SRC_DIRECT || plane < p0) {
+    if (MODE == SRC_DIRECT || plane < p0) {
         const char* p = (const char*)a.src0 +
                         (((size_t)b * a.H + y) * a.W + x) * a.C0 * sizeof(T) + plane * 64 + ch * 16;
         v = ldg16(p);
     } else {
-        // CONCAT_UP, upsampled half: channels C0.. come from bilinear x2 of src1, zero-padded.
-        int yu = y - a.padT, xu = x - a.padL;
-        ok = ok & (yu >= 0) & (yu < 2 * a.lowH) & (xu >= 0) & (xu < 2 * a.lowW);
-        yu = min(max(yu, 0), 2 * a.lowH - 1);
-        xu = min(max(xu, 0), 2 * a.lowW - 1);
-        // no contraction here either: fy must be the ROUNDED product, as in aten
-        const float fy = __fmul_rn(a.sy, (float)yu), fx = __fmul_rn(a.sx, (float)xu);
-        const int y0 = (int)fy, x0 = (int)fx;
-        const int y1 = y0 < a.lowH - 1 ? y0 + 1 : y0, x1 = x0 < a.lowW - 1 ? x0 + 1 : x0;
-        const float ly = __fsub_rn(fy, (float)y0), lx = __fsub_rn(fx, (float)x0);
-        const float hy = __fsub_rn(1.0f, ly), hx = __fsub_rn(1.0f, lx);
+        const UpCoord u = up_coord(a, y, x);
+        ok = ok & u.ok;
         const char* base = (const char*)a.src1 + (size_t)b * a.lowH * a.lowW * a.C1 * sizeof(T) +
                            (plane - p0) * 64 + ch * 16;
         const size_t pxb = (size_t)a.C1 * sizeof(T);
-        const uint4 v00 = ldg16(base + ((size_t)y0 * a.lowW + x0) * pxb);
-        const uint4 v01 = ldg16(base + ((size_t)y0 * a.lowW + x1) * pxb);
-        const uint4 v10 = ldg16(base + ((size_t)y1 * a.lowW + x0) * pxb);
-        const uint4 v11 = ldg16(base + ((size_t)y1 * a.lowW + x1) * pxb);
-        v = chunk_bilerp<T>(v00, v01, v10, v11, hx, lx, hy, ly);
+        const uint4 v00 = ldg16(base + ((size_t)u.y0 * a.lowW + u.x0) * pxb);
+        const uint4 v01 = ldg16(base + ((size_t)u.y0 * a.lowW + u.x1) * pxb);
+        const uint4 v10 = ldg16(base + ((size_t)u.y1 * a.lowW + u.x0) * pxb);
+        const uint4 v11 = ldg16(base + ((size_t)u.y1 * a.lowW + u.x1) * pxb);
+        v = chunk_bilerp<T>(v00, v01, v10, v11, u.hx, u.lx, u.hy, u.ly);
     }
     return ok ? v : make_uint4(0u, 0u, 0u, 0u);
 }
@@ -218,7 +228,7 @@ __device__ __forceinline__ uint4 gather_chunk(const ConvArgs& a, int b, int y, i
 // that may alias every later ds_read and drains it with s_waitcnt vmcnt(0) before the first
 // fragment read of the step, which would serialise the weight stream with the MFMAs.  The asm
 // form is invisible to its wait bookkeeping, so completion is waited for by hand
-// (lds_dma_wait_all) before the barrier that publishes the ring slot.  M0 is saved/restored in
+// (lds_dma_wait_all) before the barrier that publishes the data.  M0 is saved/restored in
 // the same statement (cdna_hip_programming.md 5.7).
 __device__ __forceinline__ void glds16(const char* gsrc, unsigned lds_wave_base)
 {
@@ -256,29 +266,53 @@ __device__ __forceinline__ void mma_chunk<float>(f32x4& acc, const uint4& wa, co
     acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(wa.w), __uint_as_float(xb.w), acc, 0, 0, 0);
 }
 
-template <int BN, int TH, int TW> struct ConvTile {
+enum Epilogue { EPI_PLAIN = 0, EPI_HEAD = 1, EPI_POOL = 2 };
+
+// value of the neighbouring lane (lane ^ 1) through DPP quad_perm [1,0,3,2]: no LDS crossbar
+__device__ __forceinline__ unsigned dpp_swap_pairs(unsigned v)
+{
+    return (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xF, 0xF, true);
+}
+
+// LDS map of one workgroup (<= 80 KiB so that two fit on a CU):
+//   [ in-tile | W slot 0 | spare | W slot 1 ]
+// The spare region sits between the two ring slots so that, whichever slot is idle at a plane
+// boundary, idle slot + spare form one contiguous staging area for the low-res tile of an
+// upsampled plane.
+template <int BN, int TH, int TW, int MODE> struct ConvTile {
     static constexpr int TWP = ((TW + 2 + 7) / 8) * 8;  // in-tile row pitch, multiple of 8 pixels
     static constexpr int THP = TH + 2;
     static constexpr int IN_BYTES = THP * TWP * 64;
     static constexpr int W_BYTES = 3 * BN * 64;          // one (plane, ky) step: 3 taps
-    static constexpr int LDS_BYTES = IN_BYTES + 2 * W_BYTES;  // 2-deep weight ring
+    // low-res tile of an upsampled plane: rows/cols that a (TH+2)x(TW+2) window can touch
+    static constexpr int LRH = (TH + 1) / 2 + 3, LRW = (TW + 1) / 2 + 3, LRP = ((LRW + 3) / 4) * 4;
+    static constexpr int LR_PIECES = (LRH * LRP + 15) / 16;
+    // spare bytes between the ring slots: only what the staging area needs beyond one slot
+    static constexpr int SPARE_BYTES =
+        (MODE == SRC_CONCAT_UP && LR_PIECES * 1024 > W_BYTES) ? LR_PIECES * 1024 - W_BYTES : 0;
+    static constexpr int W_STRIDE = W_BYTES + SPARE_BYTES;  // slot 1 = slot 0 + W_STRIDE
+    static constexpr int LDS_BYTES = IN_BYTES + 2 * W_BYTES + SPARE_BYTES;
+    static_assert(LDS_BYTES <= 80 * 1024, "two workgroups must fit in the CU's 160 KiB of LDS");
 };
 
-template <typename T, int BN, int TH, int TW, int MODE, bool HEAD>
+template <typename T, int BN, int TH, int TW, int MODE, int EPI>
 __global__ __launch_bounds__(256, 2) void conv3x3_mfma_kernel(const ConvArgs a)
 {
-    using Tile = ConvTile<BN, TH, TW>;
+    using Tile = ConvTile<BN, TH, TW, MODE>;
     constexpr int PL = Elem<T>::PL;
     constexpr int TWP = Tile::TWP, THP = Tile::THP;
     constexpr int WAVES_C = BN / 64, WAVES_P = 4 / WAVES_C;
     constexpr int FR = TW / 16;       // 16-pixel fragments per tile row
     constexpr int ROWS_W = 8 / FR;    // tile rows per wave
     static_assert(TH == ROWS_W * WAVES_P, "wave tile must be 64 couts x 128 pixels");
-    static_assert(!HEAD || BN == 64, "fused head needs all 64 couts in one wave");
+    static_assert(EPI != EPI_HEAD || BN == 64, "fused head needs all 64 couts in one wave");
+    static_assert(MODE == SRC_DIRECT || MODE == SRC_CONCAT_UP, "pooling is fused into the producer");
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    char* lds_in = smem;
-    char* lds_w = smem + Tile::IN_BYTES;
+    char* const lds_in = smem;
+    char* const lds_w = smem + Tile::IN_BYTES;           // slot 0; slot 1 at + W_STRIDE
+    const unsigned lds_in_addr = lds_addr_of(lds_in);
+    const unsigned lds_w_addr = lds_addr_of(lds_w);
 
     // XCD-aware, bijective block remap: blocks sharing an input tile (different cout tiles) and
     // neighbouring tiles get consecutive logical ids on ONE XCD so the re-reads hit its L2.
@@ -314,13 +348,13 @@ __global__ __launch_bounds__(256, 2) void conv3x3_mfma_kernel(const ConvArgs a)
         b_off[kx] = (wp * ROWS_W * TWP + kx + l15) * 64 + ((lc ^ swz(kx + l15)) << 4);
 
     const int nplanes = (a.C0 + a.C1) / PL;
+    const int p0 = a.C0 / PL;
     const int nsteps = nplanes * 3;
     const char* wbase = (const char*)a.wgt + (size_t)ct * BN * 64;
 
-    // weight stream: each wave moves NW 1-KiB pieces (16 LDS rows) per step by LDS-DMA.  The LDS
-    // image is lane-linear, so the XOR swizzle goes on the per-lane SOURCE chunk instead.
+    // ---- weight stream: each wave moves NW 1-KiB pieces (16 LDS rows) per step by LDS-DMA.  The
+    //      LDS image is lane-linear, so the XOR swizzle goes on the per-lane SOURCE chunk. --------
     constexpr int NW = Tile::W_BYTES / 1024 / 4;
-    const unsigned lds_w_addr = lds_addr_of(lds_w);
     int w_src_off[NW];
 #pragma unroll
     for (int j = 0; j < NW; ++j) {
@@ -332,22 +366,16 @@ __global__ __launch_bounds__(256, 2) void conv3x3_mfma_kernel(const ConvArgs a)
         const int pl = step / 3, ky = step - pl * 3;
         const char* wsrc = wbase + ((size_t)(pl * 9 + ky * 3) * a.Cout) * 64;
         const unsigned dst = __builtin_amdgcn_readfirstlane(
-            lds_w_addr + (unsigned)((step & 1) * Tile::W_BYTES + wave * NW * 1024));
+            lds_w_addr + (unsigned)((step & 1) * Tile::W_STRIDE + wave * NW * 1024));
 #pragma unroll
         for (int j = 0; j < NW; ++j) glds16(wsrc + w_src_off[j], dst + j * 1024);
     };
 
-    // ---- input-tile gather, one plane at a time ------------------------------------------------
-    // (a) planes read straight from an NHWC tensor (all DIRECT planes, the skip half of a
-    //     concat) go by LDS-DMA: piece j = 16 consecutive LDS rows (pixels) x 64 B, lane ->
-    //     (row, chunk) with the swizzle applied to the per-lane SOURCE chunk; pixels outside the
-    //     image and the row-pitch padding read a 64-byte zero page.  No VGPRs, one memory round
-    //     trip per plane.
-    // (b) pooled / bilinearly upsampled planes need arithmetic, so they go through registers,
-    //     GB chunks (4 loads each) in flight at a time.
+    // ---- in-tile gather (a): planes stored as-is in an NHWC tensor go by LDS-DMA: piece j = 16
+    //      consecutive LDS rows (pixels) x 64 B; pixels outside the image and the row-pitch padding
+    //      read a 64-byte zero page.  No VGPRs, one memory round trip per plane. -------------------
     constexpr int NPIECE = THP * TWP / 16;
     static_assert(THP * TWP % 16 == 0, "in-tile must be a whole number of 1-KiB pieces");
-    const unsigned lds_in_addr = lds_addr_of(lds_in);
     const int aH = a.H, aW = a.W;
     const char* const dma_src = (const char*)a.src0 + (size_t)b * a.H * a.W * a.C0 * sizeof(T);
     const unsigned dma_px_bytes = a.C0 * sizeof(T);
@@ -357,57 +385,75 @@ __global__ __launch_bounds__(256, 2) void conv3x3_mfma_kernel(const ConvArgs a)
         asm volatile("" : "+s"(opq));  // invariant-hoisting (it would pin ~2 VGPRs per piece)
 #pragma unroll 1
         for (int j = wave; j < NPIECE; j += 4) {
-            {
-                const int row = j * 16 + (lane >> 2) + opq;
-                const int py = row / TWP, px = row - py * TWP;
-                const int y = y0 - 1 + py, x = x0 - 1 + px;
-                const bool ok = (px < TW + 2) & (y >= 0) & (y < aH) & (x >= 0) & (x < aW);
-                // one image is < 4 GiB, so a 32-bit byte offset from the batch base is enough
-                const unsigned off = (unsigned)(y * aW + x) * dma_px_bytes + plane * 64 +
-                                     (((lane & 3) ^ swz(row)) << 4);
-                const char* src = ok ? dma_src + off : zero_page + ((lane & 3) << 4);
-                glds16(src, __builtin_amdgcn_readfirstlane(lds_in_addr + (unsigned)j * 1024u));
-            }
+            const int row = j * 16 + (lane >> 2) + opq;
+            const int py = row / TWP, px = row - py * TWP;
+            const int y = y0 - 1 + py, x = x0 - 1 + px;
+            const bool ok = (px < TW + 2) & (y >= 0) & (y < aH) & (x >= 0) & (x < aW);
+            // one image is < 4 GiB, so a 32-bit byte offset from the batch base is enough
+            const unsigned off = (unsigned)(y * aW + x) * dma_px_bytes + plane * 64 +
+                                 (((lane & 3) ^ swz(row)) << 4);
+            const char* src = ok ? dma_src + off : zero_page + ((lane & 3) << 4);
+            glds16(src, __builtin_amdgcn_readfirstlane(lds_in_addr + (unsigned)j * 1024u));
         }
-    };
-    constexpr int NCH = THP * (TW + 2) * 4;
-    constexpr int NG = (NCH + 255) / 256;
-    constexpr int GB = FIUNET_GB;  // chunks (x4 loads) in flight per thread on the register path
-    auto gather_plane_regs = [&](int plane) __attribute__((always_inline)) {
-        int opq = 0;
-        asm volatile("" : "+v"(opq));
-        const int tido = tid + opq;
-#pragma unroll
-        for (int k0 = 0; k0 < NG; k0 += GB) {
-            uint4 g[GB];
-#pragma unroll
-            for (int k = 0; k < GB; ++k) {
-                const int i = tido + (k0 + k) * 256;
-                const int pix = i >> 2, ch = i & 3;
-                const int py = pix / (TW + 2), px = pix - py * (TW + 2);
-                if (k0 + k < NG)
-                    g[k] = gather_chunk<T, MODE>(a, b, y0 - 1 + py, x0 - 1 + px, plane, ch);
-            }
-#pragma unroll
-            for (int k = 0; k < GB; ++k) {
-                const int i = tido + (k0 + k) * 256;
-                const int pix = i >> 2, ch = i & 3;
-                const int py = pix / (TW + 2), px = pix - py * (TW + 2);
-                const int row = py * TWP + px;
-                if (k0 + k < NG && i < NCH)
-                    *reinterpret_cast<uint4*>(lds_in + row * 64 + ((ch ^ swz(row)) << 4)) = g[k];
-            }
-        }
-    };
-    auto gather_plane = [&](int plane) __attribute__((always_inline)) {
-        if (MODE == SRC_DIRECT || (MODE == SRC_CONCAT_UP && plane < a.C0 / PL))
-            gather_plane_dma(plane);
-        else
-            gather_plane_regs(plane);
     };
 
+    // ---- in-tile gather (b): bilinearly upsampled planes.  The low-res source tile (<= LRH x LRW
+    //      pixels of this plane) is DMA-ed into the idle weight slot + spare region, then every
+    //      thread interpolates its chunks LDS -> LDS: one memory round trip per plane instead of
+    //      one per batch of register loads, and no VGPRs held across it. ---------------------------
+    constexpr int NCH = THP * (TW + 2) * 4;
+    int lr_y = 0, lr_x = 0;  // low-res origin of this tile's staging window
+    if (MODE == SRC_CONCAT_UP) {
+        const UpCoord u = up_coord(a, y0 - 1, x0 - 1);
+        lr_y = u.y0; lr_x = u.x0;
+    }
+    auto gather_plane_up = [&](int plane, int idle_slot) __attribute__((always_inline)) {
+        constexpr int LRP = Tile::LRP, LRH = Tile::LRH;
+        // idle slot 0: [slot0 | spare]; idle slot 1: [spare | slot1]
+        const int stg_off = idle_slot == 0 ? 0 : Tile::W_BYTES;
+        const char* const lsrc = (const char*)a.src1 +
+                                 (size_t)b * a.lowH * a.lowW * a.C1 * sizeof(T) + (plane - p0) * 64;
+        const unsigned lpx = a.C1 * sizeof(T);
+        int opq = 0;
+        asm volatile("" : "+s"(opq));
+#pragma unroll 1
+        for (int j = wave; j < Tile::LR_PIECES; j += 4) {
+            const int row = j * 16 + (lane >> 2) + opq;
+            const int r = row / LRP, c = row - r * LRP;
+            const int gy = min(lr_y + min(r, LRH - 1), a.lowH - 1), gx = min(lr_x + c, a.lowW - 1);
+            const char* src = lsrc + (unsigned)(gy * a.lowW + gx) * lpx + ((lane & 3) << 4);
+            glds16(src, __builtin_amdgcn_readfirstlane(lds_w_addr + (unsigned)(stg_off + j * 1024)));
+        }
+        lds_dma_wait_all();
+        __syncthreads();
+        const char* const stg = lds_w + stg_off;
+#pragma unroll 2
+        for (int i = tid; i < NCH; i += 256) {
+            const int pix = i >> 2, ch = i & 3;
+            const int py = pix / (TW + 2), px = pix - py * (TW + 2);
+            const int y = y0 - 1 + py, x = x0 - 1 + px;
+            const UpCoord u = up_coord(a, min(max(y, 0), aH - 1), min(max(x, 0), aW - 1));
+            const bool ok = u.ok & (y >= 0) & (y < aH) & (x >= 0) & (x < aW);
+            const int r0 = (u.y0 - lr_y) * LRP, r1 = (u.y1 - lr_y) * LRP;
+            const int c0 = u.x0 - lr_x, c1 = u.x1 - lr_x;
+            const uint4 v00 = *reinterpret_cast<const uint4*>(stg + (r0 + c0) * 64 + ch * 16);
+            const uint4 v01 = *reinterpret_cast<const uint4*>(stg + (r0 + c1) * 64 + ch * 16);
+            const uint4 v10 = *reinterpret_cast<const uint4*>(stg + (r1 + c0) * 64 + ch * 16);
+            const uint4 v11 = *reinterpret_cast<const uint4*>(stg + (r1 + c1) * 64 + ch * 16);
+            uint4 v = chunk_bilerp<T>(v00, v01, v10, v11, u.hx, u.lx, u.hy, u.ly);
+            if (!ok) v = make_uint4(0u, 0u, 0u, 0u);
+            const int row = py * TWP + px;
+            *reinterpret_cast<uint4*>(lds_in + row * 64 + ((ch ^ swz(row)) << 4)) = v;
+        }
+    };
+    auto gather_plane = [&](int plane, int idle_slot) __attribute__((always_inline)) {
+        if (MODE == SRC_DIRECT || plane < p0) gather_plane_dma(plane);
+        else gather_plane_up(plane, idle_slot);
+    };
+
+    // W(0) goes to slot 0, so slot 1 (+ spare) is the idle staging area for plane 0
     issue_w(0);
-    gather_plane(0);
+    gather_plane(0, 1);
     lds_dma_wait_all();
     __syncthreads();
 
@@ -418,7 +464,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_mfma_kernel(const ConvArgs a)
             // W(step) and the in-tile of `plane` are resident.  Stream W(step+1) into the other
             // ring slot (its last readers passed the barrier that ended step-1).
             if (step + 1 < nsteps) issue_w(step + 1);
-            const char* wcur = lds_w + (step & 1) * Tile::W_BYTES + a_off;
+            const char* wcur = lds_w + (step & 1) * Tile::W_STRIDE + a_off;
 #pragma unroll
             for (int kx = 0; kx < 3; ++kx) {
                 uint4 wa[4], xb[8];
@@ -435,10 +481,10 @@ __global__ __launch_bounds__(256, 2) void conv3x3_mfma_kernel(const ConvArgs a)
                     for (int n = 0; n < 8; ++n) mma_chunk<T>(acc[m][n], wa[m], xb[n]);
             }
             if (ky == 2 && plane + 1 < nplanes) {
-                __syncthreads();  // every wave is done reading this plane's in-tile
-                gather_plane(plane + 1);
+                __syncthreads();  // every wave is done with this plane's in-tile and with W(step)
+                gather_plane(plane + 1, step & 1);
             }
-            lds_dma_wait_all();   // this wave's pieces of W(step+1) have landed
+            lds_dma_wait_all();   // this wave's pieces of W(step+1) (and of the in-tile) landed
             __syncthreads();      // ... and so have everyone else's; in-tile writes visible
         }
     }
@@ -452,7 +498,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_mfma_kernel(const ConvArgs a)
         sh[m] = *reinterpret_cast<const float4*>(a.shift + cbase + m * 16);
     }
     float hw[3][4][4];
-    if (HEAD) {
+    if (EPI == EPI_HEAD) {
 #pragma unroll
         for (int c = 0; c < 3; ++c)
 #pragma unroll
@@ -463,12 +509,13 @@ __global__ __launch_bounds__(256, 2) void conv3x3_mfma_kernel(const ConvArgs a)
                 hw[c][m][0] = v.x; hw[c][m][1] = v.y; hw[c][m][2] = v.z; hw[c][m][3] = v.w;
             }
     }
+    const int pH = aH >> 1, pW = aW >> 1;  // EPI_POOL: MaxPool2d(2) output size (floor)
 #pragma unroll
     for (int n = 0; n < 8; ++n) {
         const int y = y0 + wp * ROWS_W + n / FR;
         const int x = x0 + (n % FR) * 16 + l15;
-        const bool ok = (y < a.H) && (x < a.W);
-        const size_t pix = ((size_t)b * a.H + y) * a.W + x;
+        const bool ok = (y < aH) && (x < aW);
+        const size_t pix = ((size_t)b * aH + y) * aW + x;
         float hsum[3] = {0.f, 0.f, 0.f};
 #pragma unroll
         for (int m = 0; m < 4; ++m) {
@@ -481,7 +528,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_mfma_kernel(const ConvArgs a)
 #pragma unroll
                 for (int j = 0; j < 4; ++j) v[j] = fmaxf(v[j], 0.f);
             }
-            if (HEAD) {
+            if (EPI == EPI_HEAD) {
 #pragma unroll
                 for (int c = 0; c < 3; ++c)
 #pragma unroll
@@ -496,15 +543,56 @@ __global__ __launch_bounds__(256, 2) void conv3x3_mfma_kernel(const ConvArgs a)
                         make_uint2(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]));
                 }
             }
+            if (EPI == EPI_POOL) {
+                // keep the post-activation values in acc: the 2x2 max below needs the row pair
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[m][n][j] = v[j];
+            }
         }
-        if (HEAD) {
+        if (EPI == EPI_HEAD) {
 #pragma unroll
             for (int c = 0; c < 3; ++c) {
                 float s = hsum[c];
                 s += __shfl_xor(s, 16);
                 s += __shfl_xor(s, 32);
                 if (c < a.head_nc && ok && lc == 0)
-                    a.head_out[(((size_t)b * a.head_nc + c) * a.H + y) * a.W + x] = s + a.head_b[c];
+                    a.head_out[(((size_t)b * a.head_nc + c) * aH + y) * aW + x] = s + a.head_b[c];
+            }
+        }
+    }
+    if (EPI == EPI_POOL) {
+        // MaxPool2d(2) of this conv's output (unet.py:28), fused here so the consumer conv reads a
+        // ready NHWC tensor by LDS-DMA: tile origins are even, a wave owns whole row pairs
+        // (fragments n and n+FR) and the column partner is the neighbouring lane (l15 ^ 1).
+        // max(round(a), round(b)) == round(max(a, b)), so this equals pooling the stored tensor.
+#pragma unroll
+        for (int n = 0; n < 8; ++n) {
+            if (((n / FR) & 1) != 0) continue;  // upper row of each pair only
+            const int y = y0 + wp * ROWS_W + n / FR;
+            const int x = x0 + (n % FR) * 16 + l15;
+            const int py = y >> 1, px = x >> 1;
+            const bool okp = (py < pH) && (px < pW) && ((l15 & 1) == 0);
+#pragma unroll
+            for (int m = 0; m < 4; ++m) {
+                T* o = (T*)a.pool_dst + (((size_t)b * pH + py) * pW + px) * a.Cout + cbase + m * 16;
+                if constexpr (sizeof(T) == 4) {
+                    float v[4];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const float cm = fmaxf(acc[m][n][j], acc[m][n + FR][j]);
+                        v[j] = fmaxf(cm, __uint_as_float(dpp_swap_pairs(__float_as_uint(cm))));
+                    }
+                    if (okp) *reinterpret_cast<float4*>(o) = make_float4(v[0], v[1], v[2], v[3]);
+                } else {
+                    // values are >= 0 (post-ReLU): packed int16 max on the rounded bf16 pairs
+                    const unsigned a0 = pk_max_i16(pack_bf16x2(acc[m][n][0], acc[m][n][1]),
+                                                   pack_bf16x2(acc[m][n + FR][0], acc[m][n + FR][1]));
+                    const unsigned a1 = pk_max_i16(pack_bf16x2(acc[m][n][2], acc[m][n][3]),
+                                                   pack_bf16x2(acc[m][n + FR][2], acc[m][n + FR][3]));
+                    const unsigned r0 = pk_max_i16(a0, dpp_swap_pairs(a0));
+                    const unsigned r1 = pk_max_i16(a1, dpp_swap_pairs(a1));
+                    if (okp) *reinterpret_cast<uint2*>(o) = make_uint2(r0, r1);
+                }
             }
         }
     }

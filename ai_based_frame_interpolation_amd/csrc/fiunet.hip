@@ -9,7 +9,6 @@
 // gfx950 only; no CPU fallback: every entry point either launches HIP kernels or returns an error.
 #include "../../include/fiunet.h"
 #include "pointwise.hip.h"
-#include "conv3x3_pers.hip.h"
 
 #include <algorithm>
 #include <cmath>
@@ -47,10 +46,15 @@ const char* const kBlockPrefix[9] = {
 const int kCout[NCONV] = {64, 64, 128, 128, 256, 256, 512, 512, 512, 512, 512, 256, 256, 128, 128, 64, 64, 64};
 const int kLevel[NCONV] = {0, 0, 1, 1, 2, 2, 3, 3, 4, 4, 3, 3, 2, 2, 1, 1, 0, 0};
 // gather mode and sources (activation indices) of each conv; conv 0 is the fp32 stem kernel
+// SRC_POOL here means "reads MaxPool2d(2) of its source": the pooled tensor is written by the
+// producer conv's epilogue (EPI_POOL) -- or by maxpool2_kernel on the ablation path -- and the
+// consumer then gathers it like any other NHWC tensor.
 const int kMode[NCONV] = {-1, SRC_DIRECT, SRC_POOL, SRC_DIRECT, SRC_POOL, SRC_DIRECT, SRC_POOL,
                           SRC_DIRECT, SRC_POOL, SRC_DIRECT, SRC_CONCAT_UP, SRC_DIRECT,
                           SRC_CONCAT_UP, SRC_DIRECT, SRC_CONCAT_UP, SRC_DIRECT, SRC_CONCAT_UP,
                           SRC_DIRECT};
+// producer conv i -> index of the pooled copy it also emits (convs 1,3,5,7 = x1..x4), else -1
+const int kPoolOut[NCONV] = {-1, 0, -1, 1, -1, 2, -1, 3, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1};
 const int kSrc0[NCONV] = {-1, 0, 1, 2, 3, 4, 5, 6, 7, 8, 7, 10, 5, 12, 3, 14, 1, 16};
 const int kSrc1[NCONV] = {-1, -1, -1, -1, -1, -1, -1, -1, -1, -1, 9, -1, 11, -1, 13, -1, 15, -1};
 
@@ -76,6 +80,7 @@ inline size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
 struct Plan {
     int hs[5], ws[5];
     size_t act_off[NCONV];
+    size_t pool_off[4];  // MaxPool2d(2) of x1..x4: kCout[2k+1] channels at level k+1
     size_t scratch_off;
     size_t total;
 };
@@ -91,7 +96,11 @@ bool make_plan(int B, int H, int W, int precision, Plan& p)
         p.act_off[i] = off;
         off += align256((size_t)B * p.hs[kLevel[i]] * p.ws[kLevel[i]] * kCout[i] * es);
     }
-    p.scratch_off = off;  // ablation path: pooled tensor / concat tensor (<= 128 ch at level 0)
+    for (int k = 0; k < 4; ++k) {
+        p.pool_off[k] = off;
+        off += align256((size_t)B * p.hs[k + 1] * p.ws[k + 1] * kCout[2 * k + 1] * es);
+    }
+    p.scratch_off = off;  // ablation path: concat tensor (<= 128 ch at level 0)
     off += align256((size_t)B * H * W * 128 * es);
     p.total = off;
     return true;
@@ -138,14 +147,14 @@ void free_weights(fiunet_ctx* ctx)
 
 thread_local std::string* g_name_out = nullptr;  // where the next conv launch reports its kernel
 
-template <typename T, int BN, int TH, int TW, int MODE, bool HEAD>
+template <typename T, int BN, int TH, int TW, int MODE, int EPI>
 int launch_conv_cfg(ConvArgs a, hipStream_t s)
 {
-    using Tile = ConvTile<BN, TH, TW>;
+    using Tile = ConvTile<BN, TH, TW, MODE>;
     if (g_name_out) {
         char buf[128];
         std::snprintf(buf, sizeof buf, "conv3x3_mfma_kernel<%s,%d,%d,%d,%d,%d>",
-                      sizeof(T) == 2 ? "bf16" : "f32", BN, TH, TW, MODE, (int)HEAD);
+                      sizeof(T) == 2 ? "bf16" : "f32", BN, TH, TW, MODE, EPI);
         *g_name_out = buf;
     }
     a.tilesX = (a.W + TW - 1) / TW;
@@ -156,11 +165,11 @@ int launch_conv_cfg(ConvArgs a, hipStream_t s)
     static bool lds_attr_set = false;  // > 64 KiB of dynamic LDS needs the opt-in attribute
     if (!lds_attr_set) {
         HIP_TRY(hipFuncSetAttribute(
-            reinterpret_cast<const void*>(&conv3x3_mfma_kernel<T, BN, TH, TW, MODE, HEAD>),
+            reinterpret_cast<const void*>(&conv3x3_mfma_kernel<T, BN, TH, TW, MODE, EPI>),
             hipFuncAttributeMaxDynamicSharedMemorySize, Tile::LDS_BYTES));
         lds_attr_set = true;
     }
-    hipLaunchKernelGGL((conv3x3_mfma_kernel<T, BN, TH, TW, MODE, HEAD>), dim3((unsigned)nblk),
+    hipLaunchKernelGGL((conv3x3_mfma_kernel<T, BN, TH, TW, MODE, EPI>), dim3((unsigned)nblk),
                        dim3(256), Tile::LDS_BYTES, s, a);
     HIP_TRY(hipGetLastError());
     return FIUNET_OK;
@@ -171,92 +180,32 @@ inline long long padded_area(int H, int W, int TH, int TW)
     return (long long)((H + TH - 1) / TH) * TH * ((W + TW - 1) / TW) * TW;
 }
 
-template <typename T, int MODE>
-int launch_conv_mode(const ConvArgs& a, bool head, hipStream_t s)
+template <typename T, int MODE, int EPI> int launch_conv_shape(const ConvArgs& a, hipStream_t s)
 {
     if (a.Cout == 64) {
         const bool wide = padded_area(a.H, a.W, 16, 32) <= padded_area(a.H, a.W, 32, 16);
-        if constexpr (MODE == SRC_DIRECT) {
-            if (head)
-                return wide ? launch_conv_cfg<T, 64, 16, 32, MODE, true>(a, s)
-                            : launch_conv_cfg<T, 64, 32, 16, MODE, true>(a, s);
-        }
-        if constexpr (MODE != SRC_POOL)
-            return wide ? launch_conv_cfg<T, 64, 16, 32, MODE, false>(a, s)
-                        : launch_conv_cfg<T, 64, 32, 16, MODE, false>(a, s);
-        return fail(FIUNET_ERR_INVALID_ARG, "no pooled conv variant with 64 couts");
+        return wide ? launch_conv_cfg<T, 64, 16, 32, MODE, EPI>(a, s)
+                    : launch_conv_cfg<T, 64, 32, 16, MODE, EPI>(a, s);
     }
-    if (a.Cout % 128 != 0) return fail(FIUNET_ERR_INVALID_ARG, "Cout must be 64 or k*128");
-    const bool wide = padded_area(a.H, a.W, 8, 32) <= padded_area(a.H, a.W, 16, 16);
-    return wide ? launch_conv_cfg<T, 128, 8, 32, MODE, false>(a, s)
-                : launch_conv_cfg<T, 128, 16, 16, MODE, false>(a, s);
+    if constexpr (EPI != EPI_HEAD) {
+        if (a.Cout % 128 != 0) return fail(FIUNET_ERR_INVALID_ARG, "Cout must be 64 or k*128");
+        const bool wide = padded_area(a.H, a.W, 8, 32) <= padded_area(a.H, a.W, 16, 16);
+        return wide ? launch_conv_cfg<T, 128, 8, 32, MODE, EPI>(a, s)
+                    : launch_conv_cfg<T, 128, 16, 16, MODE, EPI>(a, s);
+    }
+    return fail(FIUNET_ERR_INVALID_ARG, "fused head needs Cout == 64");
 }
 
-int g_num_cus = 0;  // multiProcessorCount of the context's device (set in fiunet_create)
-
-template <typename T, int BN, int MODE, bool HEAD>
-int launch_pers_cfg(ConvArgs a, hipStream_t s)
-{
-    using Tile = PersTile<BN>;
-    a.tilesX = (a.W + Tile::TW - 1) / Tile::TW;
-    a.tilesY = (a.H + Tile::TH - 1) / Tile::TH;
-    a.nct = a.Cout / BN;
-    const long long total = (long long)a.B * a.tilesX * a.tilesY * a.nct;
-    if (total <= 0 || total > 0x7fffffffLL) return fail(FIUNET_ERR_INVALID_ARG, "conv grid too large");
-    if (g_name_out) {
-        char buf[128];
-        std::snprintf(buf, sizeof buf, "conv3x3_pers_kernel<%s,%d,%d,%d>",
-                      sizeof(T) == 2 ? "bf16" : "f32", BN, MODE, (int)HEAD);
-        *g_name_out = buf;
-    }
-    static bool lds_attr_set = false;
-    if (!lds_attr_set) {
-        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_pers_kernel<T, BN, MODE, HEAD>),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, Tile::LDS_BYTES));
-        lds_attr_set = true;
-    }
-    const int grid = std::max(8, (g_num_cus / 8) * 8);  // one persistent workgroup per CU
-    hipLaunchKernelGGL((conv3x3_pers_kernel<T, BN, MODE, HEAD>), dim3(grid), dim3(512),
-                       Tile::LDS_BYTES, s, a);
-    HIP_TRY(hipGetLastError());
-    return FIUNET_OK;
-}
-
-template <typename T, int MODE> int launch_pers_mode(const ConvArgs& a, bool head, hipStream_t s)
-{
-    if (a.Cout == 64) {
-        if constexpr (MODE == SRC_DIRECT) {
-            if (head) return launch_pers_cfg<T, 64, MODE, true>(a, s);
-        }
-        if constexpr (MODE != SRC_POOL) return launch_pers_cfg<T, 64, MODE, false>(a, s);
-        return fail(FIUNET_ERR_INVALID_ARG, "no pooled conv variant with 64 couts");
-    }
-    if (a.Cout % 128 != 0) return fail(FIUNET_ERR_INVALID_ARG, "Cout must be 64 or k*128");
-    return launch_pers_cfg<T, 128, MODE, false>(a, s);
-}
-
-template <typename T> int launch_pers(const ConvArgs& a, int mode, bool head, hipStream_t s)
+// mode: SRC_DIRECT | SRC_CONCAT_UP; epi: EPI_PLAIN | EPI_HEAD | EPI_POOL (direct sources only)
+template <typename T> int launch_conv(const ConvArgs& a, int mode, int epi, hipStream_t s)
 {
     constexpr int PL = Elem<T>::PL;
     if (a.C0 % PL || a.C1 % PL) return fail(FIUNET_ERR_INVALID_ARG, "channels not a plane multiple");
-    switch (mode) {
-    case SRC_DIRECT: return launch_pers_mode<T, SRC_DIRECT>(a, head, s);
-    case SRC_POOL: return launch_pers_mode<T, SRC_POOL>(a, head, s);
-    case SRC_CONCAT_UP: return launch_pers_mode<T, SRC_CONCAT_UP>(a, head, s);
-    }
-    return fail(FIUNET_ERR_INVALID_ARG, "bad gather mode");
-}
-
-template <typename T> int launch_conv(const ConvArgs& a, int mode, bool head, hipStream_t s)
-{
-    constexpr int PL = Elem<T>::PL;
-    if (a.C0 % PL || a.C1 % PL) return fail(FIUNET_ERR_INVALID_ARG, "channels not a plane multiple");
-    switch (mode) {
-    case SRC_DIRECT: return launch_conv_mode<T, SRC_DIRECT>(a, head, s);
-    case SRC_POOL: return launch_conv_mode<T, SRC_POOL>(a, head, s);
-    case SRC_CONCAT_UP: return launch_conv_mode<T, SRC_CONCAT_UP>(a, head, s);
-    }
-    return fail(FIUNET_ERR_INVALID_ARG, "bad gather mode");
+    if (mode == SRC_CONCAT_UP && epi == EPI_PLAIN) return launch_conv_shape<T, SRC_CONCAT_UP, EPI_PLAIN>(a, s);
+    if (mode == SRC_DIRECT && epi == EPI_PLAIN) return launch_conv_shape<T, SRC_DIRECT, EPI_PLAIN>(a, s);
+    if (mode == SRC_DIRECT && epi == EPI_HEAD) return launch_conv_shape<T, SRC_DIRECT, EPI_HEAD>(a, s);
+    if (mode == SRC_DIRECT && epi == EPI_POOL) return launch_conv_shape<T, SRC_DIRECT, EPI_POOL>(a, s);
+    return fail(FIUNET_ERR_INVALID_ARG, "unsupported gather/epilogue combination");
 }
 
 inline unsigned grid_for(size_t n) { return (unsigned)std::min<size_t>((n + 255) / 256, 256 * 32); }
@@ -317,7 +266,17 @@ int forward_impl(fiunet_ctx* ctx, const float* f1, const float* f2, float* out, 
         a.src0 = act(kSrc0[i]);
         a.C0 = kCout[kSrc0[i]];
         if (mode == SRC_POOL) {
-            a.s0H = p.hs[lv - 1]; a.s0W = p.ws[lv - 1];
+            // MaxPool2d(2) of the source (unet.py:28): already materialised by the producer's
+            // epilogue (EPI_POOL below), or by maxpool2_kernel right here on the ablation path
+            T* pooled = (T*)(ws + p.pool_off[lv - 1]);
+            if (unfused) {
+                const size_t n = (size_t)B * a.H * a.W * (a.C0 * sizeof(T) / 16);
+                hipLaunchKernelGGL((maxpool2_kernel<T>), dim3(grid_for(n)), dim3(256), 0, s,
+                                   (const T*)a.src0, pooled, B, p.hs[lv - 1], p.ws[lv - 1], a.C0);
+                HIP_TRY(hipGetLastError());
+            }
+            a.src0 = pooled;
+            mode = SRC_DIRECT;
         } else if (mode == SRC_CONCAT_UP) {
             a.src1 = act(kSrc1[i]);
             a.C1 = kCout[kSrc1[i]];
@@ -329,27 +288,24 @@ int forward_impl(fiunet_ctx* ctx, const float* f1, const float* f2, float* out, 
             a.sx = 2 * a.lowW > 1 ? (float)(a.lowW - 1) / (float)(2 * a.lowW - 1) : 0.f;
         }
         if (a.C0 + a.C1 != cw.cin) return fail(FIUNET_ERR_INVALID_ARG, "internal: channel plan mismatch");
-        if (unfused && mode == SRC_POOL) {
-            const size_t n = (size_t)B * a.H * a.W * (a.C0 * sizeof(T) / 16);
-            hipLaunchKernelGGL((maxpool2_kernel<T>), dim3(grid_for(n)), dim3(256), 0, s,
-                               (const T*)a.src0, scratch, B, a.s0H, a.s0W, a.C0);
-            HIP_TRY(hipGetLastError());
-            a.src0 = scratch; mode = SRC_DIRECT;
-        } else if (unfused && mode == SRC_CONCAT_UP) {
+        if (unfused && mode == SRC_CONCAT_UP) {
             const size_t n = (size_t)B * a.H * a.W * ((a.C0 + a.C1) * sizeof(T) / 16);
             hipLaunchKernelGGL((upcat_kernel<T>), dim3(grid_for(n)), dim3(256), 0, s, a, scratch);
             HIP_TRY(hipGetLastError());
             a.src0 = scratch; a.C0 = a.C0 + a.C1; a.C1 = 0; a.src1 = nullptr; mode = SRC_DIRECT;
         }
-        bool head = false;
+        int epi = EPI_PLAIN;
+        if (kPoolOut[i] >= 0 && !unfused) {  // also emit MaxPool2d(2) of this output (unet.py:28)
+            epi = EPI_POOL;
+            a.pool_dst = ws + p.pool_off[kPoolOut[i]];
+        }
         if (i == NCONV - 1 && !unfused) {  // fuse OutConv (unet.py:60) into the last epilogue
-            head = true;
+            epi = EPI_HEAD;
             a.head_w = ctx->head_w; a.head_b = ctx->head_b; a.head_out = out; a.head_nc = ctx->cf;
             if (!(ctx->flags & FIUNET_OPT_KEEP_ALL)) a.dst = nullptr;
         }
         g_name_out = ev ? &ctx->layer_name[i] : nullptr;
-        const int rc = (ctx->flags & FIUNET_OPT_CLASSIC) ? launch_conv<T>(a, mode, head, s)
-                                                         : launch_pers<T>(a, mode, head, s);
+        const int rc = launch_conv<T>(a, mode, epi, s);
         g_name_out = nullptr;
         if (rc != FIUNET_OK) return rc;
         if (ev) {
@@ -392,9 +348,6 @@ int fiunet_create(fiunet_ctx** out_ctx, int device_id, int frame_channels, int b
     if (!c) return fail(FIUNET_ERR_INVALID_ARG, "out of host memory");
     c->device = device_id;
     c->cf = frame_channels;
-    hipDeviceProp_t prop;
-    HIP_TRY(hipGetDeviceProperties(&prop, device_id));
-    g_num_cus = prop.multiProcessorCount;
     *out_ctx = c;
     return FIUNET_OK;
 }

@@ -122,9 +122,8 @@ class FrameInterpolationUNet(nn.Module):
         """Call after editing parameters in place so the next forward re-uploads them."""
         self._ctx_dirty = True
 
-    def set_options(self, *, unfused: bool = False, keep_all: bool = False, classic: bool = False):
-        self._options = ((_native.OPT_UNFUSED if unfused else 0) | (_native.OPT_KEEP_ALL if keep_all else 0)
-                         | (_native.OPT_CLASSIC if classic else 0))
+    def set_options(self, *, unfused: bool = False, keep_all: bool = False):
+        self._options = (_native.OPT_UNFUSED if unfused else 0) | (_native.OPT_KEEP_ALL if keep_all else 0)
         if self._ctx is not None:
             self._ctx.set_options(self._options)
 
@@ -204,8 +203,7 @@ class FrameInterpolationUNet(nn.Module):
         """Parity-test hook: run one forward keeping every stage and return
         ({tap name: fp32 NCHW tensor}, output)."""
         saved = self._options
-        self.set_options(unfused=bool(saved & _native.OPT_UNFUSED), keep_all=True,
-                         classic=bool(saved & _native.OPT_CLASSIC))
+        self.set_options(unfused=bool(saved & _native.OPT_UNFUSED), keep_all=True)
         try:
             out = self.forward(frame1, frame2)
             b, _, h, w = frame1.shape

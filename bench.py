@@ -78,7 +78,6 @@ def main():
     ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--unfused", action="store_true", help="ablation: separate pool/upsample/head kernels")
-    ap.add_argument("--classic", action="store_true", help="A/B: non-persistent conv kernel")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -117,7 +116,7 @@ def main():
             elif name.endswith("running_var"):
                 buf.uniform_(0.5, 1.5)
     model = model.to(dev).eval()
-    model.set_options(unfused=args.unfused, classic=args.classic)
+    model.set_options(unfused=args.unfused)
 
     gen = torch.Generator(device=dev).manual_seed(1 + rank)
     f1 = torch.rand(b, 1, h, w, device=dev, generator=gen) * 2 - 1
@@ -195,7 +194,7 @@ def main():
         "scaling": "weak", "vs_baseline": None, "dtype": args.precision, "data": "synthetic",
         "config": {"workload": f"batch={b} {w}x{h} synthetic frame pairs per GPU, {args.precision} "
                                f"MFMA conv path, random-init UNet(2->1, bilinear) weights",
-                   "batch_per_gpu": b, "height": h, "width": w, "fused": not args.unfused, "conv_kernel": "classic" if args.classic else "persistent",
+                   "batch_per_gpu": b, "height": h, "width": w, "fused": not args.unfused,
                    "parallelism": f"frame-pair shard x{world}, no data-path collective"},
         "roofline": roofline,
     }

@@ -43,10 +43,8 @@ enum fiunet_precision { FIUNET_FP32 = 0, FIUNET_BF16 = 1 };
 enum fiunet_option {
     FIUNET_OPT_UNFUSED = 1, /* ablation: run max-pool, upsample+pad+concat and the 1x1 head as
                                separate kernels instead of fusing them into the consumer conv */
-    FIUNET_OPT_KEEP_ALL = 2,/* also store the last 64-ch activation (tap 17) that the fused 1x1
+    FIUNET_OPT_KEEP_ALL = 2 /* also store the last 64-ch activation (tap 17) that the fused 1x1
                                head otherwise keeps in registers; for fiunet_debug_read_activation */
-    FIUNET_OPT_CLASSIC = 4  /* A/B: run the non-persistent conv kernel (4 waves, 2 workgroups/CU)
-                               instead of the persistent double-buffered one */
 };
 
 typedef struct fiunet_ctx fiunet_ctx;
