@@ -1,0 +1,83 @@
+"""Summarise rocprofv3 PMC passes of `bench.py` into profiles/pmc_summary.json + a text table.
+
+usage: python tools/pmc_summary.py gpurun_out/pmc profiles/r01_pmc
+Each pass directory holds one *_counter_collection.csv (one row per dispatch and counter).
+Corrections per /opt/skills/guides/MI355X_MICROARCH.md (HBM / rocprofv3): FETCH_SIZE and
+WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE counts 128-B requests as 64 B for wide coalesced
+streams, so read bytes = 2 * FETCH_SIZE * 1024 (upper bound when part of the stream is narrow);
+WRITE_SIZE is exact for 16-B-per-lane stores (ours are 8-16 B per lane: treated as exact).
+"""
+import csv, glob, json, os, re, sys
+from collections import defaultdict
+
+src, out = sys.argv[1], sys.argv[2]
+
+def load(pass_name):
+    files = glob.glob(os.path.join(src, pass_name, "*", "*_counter_collection.csv"))
+    rows = []
+    for f in files:
+        rows += list(csv.DictReader(open(f)))
+    disp = defaultdict(dict)
+    for r in rows:
+        d = disp[int(r["Dispatch_Id"])]
+        d["name"] = r["Kernel_Name"]
+        d["grid"] = int(r["Grid_Size"])
+        d["lds"] = int(r["LDS_Block_Size"]); d["vgpr"] = int(r["VGPR_Count"])
+        d["t"] = (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) * 1e-9
+        d[r["Counter_Name"]] = d.get(r["Counter_Name"], 0.0) + float(r["Counter_Value"])
+    # the forward = stem + 17 convs; keep the LAST complete forward
+    ids = sorted(k for k, v in disp.items() if "fiunet" in v["name"] and ("conv3x3" in v["name"]))
+    last = ids[-18:]
+    return [disp[i] for i in last]
+
+def short(n):
+    m = re.search(r"conv3x3_(first|mfma)_kernelI(DF16b|f)((?:Li\d+E)+)", n)
+    if not m:
+        return n[:40]
+    nums = re.findall(r"Li(\d+)E", m.group(3))
+    return f"conv3x3_{m.group(1)}<{'bf16' if m.group(2)=='DF16b' else 'f32'},{','.join(nums)}>"
+
+fetch, write, sq = load("fetch"), load("write"), load("sq")
+stages = []
+for i in range(18):
+    f, w, s = fetch[i], write[i], sq[i]
+    assert f["name"] == w["name"] == s["name"]
+    rd = 2.0 * f["FETCH_SIZE"] * 1024.0
+    wr = w["WRITE_SIZE"] * 1024.0
+    act = s["GRBM_GUI_ACTIVE"] / 8.0            # summed over the 8 XCDs
+    simd_cycles = act * 1024.0                  # 256 CUs x 4 SIMDs
+    st = {
+        "stage": i, "kernel": short(f["name"]), "grid": f["grid"], "lds_bytes": f["lds"], "vgpr": f["vgpr"],
+        "dur_ms_fetch_pass": round(f["t"] * 1e3, 4), "dur_ms_sq_pass": round(s["t"] * 1e3, 4),
+        "hbm_read_bytes": rd, "hbm_write_bytes": wr, "hbm_bytes": rd + wr,
+        "hbm_gbs": round((rd + wr) / f["t"] / 1e9, 1),
+        "eff_clock_ghz": round(act / s["t"] / 1e9, 3),
+        "mfma_busy_frac": round(s["SQ_VALU_MFMA_BUSY_CYCLES"] / simd_cycles, 4),
+        "lds_bank_conflict_per_active": round(s["SQ_LDS_BANK_CONFLICT"] / max(s["SQ_LDS_IDX_ACTIVE"], 1), 4),
+        "wave_wait_any_frac": round(s["SQ_WAIT_ANY"] / max(s["SQ_WAVE_CYCLES"], 1), 4),
+        "wave_wait_inst_frac": round(s["SQ_WAIT_INST_ANY"] / max(s["SQ_WAVE_CYCLES"], 1), 4),
+        "wave_active_inst_frac": round(s["SQ_ACTIVE_INST_ANY"] / max(s["SQ_WAVE_CYCLES"], 1), 4),
+    }
+    stages.append(st)
+
+by_kernel = defaultdict(lambda: {"launches": 0, "hbm_bytes": 0.0})
+for st in stages:
+    k = by_kernel[st["kernel"]]
+    k["launches"] += 1; k["hbm_bytes"] += st["hbm_bytes"]
+summary = {k: {"launches_per_forward": v["launches"], "hbm_bytes_per_launch": v["hbm_bytes"] / v["launches"]}
+           for k, v in by_kernel.items()}
+os.makedirs(os.path.dirname(out) or ".", exist_ok=True)
+json.dump({"stages": stages, "by_kernel": summary}, open(out + "_stages.json", "w"), indent=1)
+with open(out + "_table.txt", "w") as fh:
+    hdr = f"{'stage':>5} {'kernel':40s} {'ms':>7} {'rd GB':>7} {'wr GB':>7} {'GB/s':>7} {'clkGHz':>6} {'mfma%':>6} {'ldsconf':>7} {'wait%':>6} {'winst%':>6}"
+    print(hdr); fh.write(hdr + "\n")
+    for st in stages:
+        line = (f"{st['stage']:5d} {st['kernel']:40s} {st['dur_ms_fetch_pass']:7.3f} {st['hbm_read_bytes']/1e9:7.3f} "
+                f"{st['hbm_write_bytes']/1e9:7.3f} {st['hbm_gbs']:7.0f} {st['eff_clock_ghz']:6.2f} {100*st['mfma_busy_frac']:6.1f} "
+                f"{st['lds_bank_conflict_per_active']:7.3f} {100*st['wave_wait_any_frac']:6.1f} {100*st['wave_wait_inst_frac']:6.1f}")
+        print(line); fh.write(line + "\n")
+    tot = sum(s["hbm_bytes"] for s in stages)
+    line = f"total HBM bytes per forward (B=8): {tot/1e9:.2f} GB; algorithmic fused-ideal: {8*2146.1e6*2/1e9:.2f} GB"
+    print(line); fh.write(line + "\n")
+# bench.py reads profiles/pmc_summary.json for roofline.traffic
+json.dump(summary, open(os.path.join(os.path.dirname(out) or ".", "pmc_summary.json"), "w"), indent=1)
