@@ -43,14 +43,25 @@ typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 
 enum SrcMode { SRC_DIRECT = 0, SRC_POOL = 1 /* host-side tag only */, SRC_CONCAT_UP = 2 };
 
+// Activation layout in HBM: plane-major blocked channels-last, [B][C/PL][H][W][PL] with one
+// 64-byte "plane" record per pixel (PL = 32 bf16 / 16 fp32 channels).  A tile row of one plane is
+// one contiguous run of (TW+2)*64 bytes, so the LDS-DMA gather of a plane touches every 128-B line
+// once and in full (with plain NHWC the two 64-B halves of a 64-channel pixel were fetched by two
+// gathers microseconds apart and the line was re-read from HBM when the store stream had evicted
+// it).  Byte offset of (plane, y, x) inside one image:
+__device__ __forceinline__ size_t blk_off(int plane, int y, int x, int H, int W)
+{
+    return (((size_t)plane * H + y) * W + x) * 64;
+}
+
 struct ConvArgs {
-    const void* src0;    // [B][H][W][C0]
-    const void* src1;    // CONCAT_UP: low-res [B][lowH][lowW][C1], bilinearly upsampled on the fly
+    const void* src0;    // [B][C0/PL][H][W][PL]
+    const void* src1;    // CONCAT_UP: low-res [B][C1/PL][lowH][lowW][PL], bilinearly upsampled on the fly
     const void* wgt;     // [Cin/PL][9][Cout][PL]  (plane-major, then tap, cout, channel-in-plane)
     const float* scale;  // [Cout]  gamma / sqrt(var + eps)
     const float* shift;  // [Cout]  beta - mean * scale
-    void* dst;           // [B][H][W][Cout] or nullptr (fused head only)
-    void* pool_dst;      // EPI_POOL: [B][H/2][W/2][Cout], MaxPool2d(2) of dst
+    void* dst;           // [B][Cout/PL][H][W][PL] or nullptr (fused head only)
+    void* pool_dst;      // EPI_POOL: [B][Cout/PL][H/2][W/2][PL], MaxPool2d(2) of dst
     int B, H, W;         // conv input == output spatial size
     int C0, C1, Cout;
     int lowH, lowW;      // CONCAT_UP: spatial size of src1
@@ -205,19 +216,18 @@ __device__ __forceinline__ uint4 gather_chunk(const ConvArgs& a, int b, int y, i
     const int p0 = a.C0 / PL;
     uint4 v;
     if (MODE == SRC_DIRECT || plane < p0) {
-        const char* p = (const char*)a.src0 +
-                        (((size_t)b * a.H + y) * a.W + x) * a.C0 * sizeof(T) + plane * 64 + ch * 16;
+        const char* p = (const char*)a.src0 + (size_t)b * a.H * a.W * a.C0 * sizeof(T) +
+                        blk_off(plane, y, x, a.H, a.W) + ch * 16;
         v = ldg16(p);
     } else {
         const UpCoord u = up_coord(a, y, x);
         ok = ok & u.ok;
-        const char* base = (const char*)a.src1 + (size_t)b * a.lowH * a.lowW * a.C1 * sizeof(T) +
-                           (plane - p0) * 64 + ch * 16;
-        const size_t pxb = (size_t)a.C1 * sizeof(T);
-        const uint4 v00 = ldg16(base + ((size_t)u.y0 * a.lowW + u.x0) * pxb);
-        const uint4 v01 = ldg16(base + ((size_t)u.y0 * a.lowW + u.x1) * pxb);
-        const uint4 v10 = ldg16(base + ((size_t)u.y1 * a.lowW + u.x0) * pxb);
-        const uint4 v11 = ldg16(base + ((size_t)u.y1 * a.lowW + u.x1) * pxb);
+        const char* base = (const char*)a.src1 + (size_t)b * a.lowH * a.lowW * a.C1 * sizeof(T) + ch * 16;
+        const int q = plane - p0;
+        const uint4 v00 = ldg16(base + blk_off(q, u.y0, u.x0, a.lowH, a.lowW));
+        const uint4 v01 = ldg16(base + blk_off(q, u.y0, u.x1, a.lowH, a.lowW));
+        const uint4 v10 = ldg16(base + blk_off(q, u.y1, u.x0, a.lowH, a.lowW));
+        const uint4 v11 = ldg16(base + blk_off(q, u.y1, u.x1, a.lowH, a.lowW));
         v = chunk_bilerp<T>(v00, v01, v10, v11, u.hx, u.lx, u.hy, u.ly);
     }
     return ok ? v : make_uint4(0u, 0u, 0u, 0u);
@@ -378,7 +388,6 @@ __global__ __launch_bounds__(256, 2) void conv3x3_mfma_kernel(const ConvArgs a)
     static_assert(THP * TWP % 16 == 0, "in-tile must be a whole number of 1-KiB pieces");
     const int aH = a.H, aW = a.W;
     const char* const dma_src = (const char*)a.src0 + (size_t)b * a.H * a.W * a.C0 * sizeof(T);
-    const unsigned dma_px_bytes = a.C0 * sizeof(T);
     const char* const zero_page = (const char*)a.zero_page;
     auto gather_plane_dma = [&](int plane) __attribute__((always_inline)) {
         int opq = 0;  // opaque zero: keeps the per-piece address math out of the K loop's
@@ -390,7 +399,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_mfma_kernel(const ConvArgs a)
             const int y = y0 - 1 + py, x = x0 - 1 + px;
             const bool ok = (px < TW + 2) & (y >= 0) & (y < aH) & (x >= 0) & (x < aW);
             // one image is < 4 GiB, so a 32-bit byte offset from the batch base is enough
-            const unsigned off = (unsigned)(y * aW + x) * dma_px_bytes + plane * 64 +
+            const unsigned off = (unsigned)((plane * aH + y) * aW + x) * 64u +
                                  (((lane & 3) ^ swz(row)) << 4);
             const char* src = ok ? dma_src + off : zero_page + ((lane & 3) << 4);
             glds16(src, __builtin_amdgcn_readfirstlane(lds_in_addr + (unsigned)j * 1024u));
@@ -411,9 +420,8 @@ __global__ __launch_bounds__(256, 2) void conv3x3_mfma_kernel(const ConvArgs a)
         constexpr int LRP = Tile::LRP, LRH = Tile::LRH;
         // idle slot 0: [slot0 | spare]; idle slot 1: [spare | slot1]
         const int stg_off = idle_slot == 0 ? 0 : Tile::W_BYTES;
-        const char* const lsrc = (const char*)a.src1 +
-                                 (size_t)b * a.lowH * a.lowW * a.C1 * sizeof(T) + (plane - p0) * 64;
-        const unsigned lpx = a.C1 * sizeof(T);
+        const char* const lsrc = (const char*)a.src1 + (size_t)b * a.lowH * a.lowW * a.C1 * sizeof(T) +
+                                 (size_t)(plane - p0) * a.lowH * a.lowW * 64;
         int opq = 0;
         asm volatile("" : "+s"(opq));
 #pragma unroll 1
@@ -421,7 +429,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_mfma_kernel(const ConvArgs a)
             const int row = j * 16 + (lane >> 2) + opq;
             const int r = row / LRP, c = row - r * LRP;
             const int gy = min(lr_y + min(r, LRH - 1), a.lowH - 1), gx = min(lr_x + c, a.lowW - 1);
-            const char* src = lsrc + (unsigned)(gy * a.lowW + gx) * lpx + ((lane & 3) << 4);
+            const char* src = lsrc + (unsigned)(gy * a.lowW + gx) * 64u + ((lane & 3) << 4);
             glds16(src, __builtin_amdgcn_readfirstlane(lds_w_addr + (unsigned)(stg_off + j * 1024)));
         }
         lds_dma_wait_all();
@@ -491,6 +499,12 @@ __global__ __launch_bounds__(256, 2) void conv3x3_mfma_kernel(const ConvArgs a)
 
     // ---- epilogue: y = relu(acc * scale + shift); lane holds couts cbase+m*16+lc*4+{0..3} ----
     const int cbase = ct * BN + wc * 64 + lc * 4;
+    // blocked output: cout c lives in plane c / PL at byte (c % PL) * sizeof(T) of the pixel record
+    const size_t img_bytes = (size_t)aH * aW * a.Cout * sizeof(T);
+    auto out_off = [&](int m, int hh, int ww, int y, int x) __attribute__((always_inline)) {
+        const int c = cbase + m * 16;
+        return blk_off(c / PL, y, x, hh, ww) + (size_t)(c % PL) * sizeof(T);
+    };
     float4 sc[4], sh[4];
 #pragma unroll
     for (int m = 0; m < 4; ++m) {
@@ -515,7 +529,6 @@ __global__ __launch_bounds__(256, 2) void conv3x3_mfma_kernel(const ConvArgs a)
         const int y = y0 + wp * ROWS_W + n / FR;
         const int x = x0 + (n % FR) * 16 + l15;
         const bool ok = (y < aH) && (x < aW);
-        const size_t pix = ((size_t)b * aH + y) * aW + x;
         float hsum[3] = {0.f, 0.f, 0.f};
 #pragma unroll
         for (int m = 0; m < 4; ++m) {
@@ -535,7 +548,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_mfma_kernel(const ConvArgs a)
                     for (int j = 0; j < 4; ++j) hsum[c] = fmaf(v[j], hw[c][m][j], hsum[c]);
             }
             if (ok && a.dst) {
-                T* o = (T*)a.dst + pix * a.Cout + cbase + m * 16;
+                char* o = (char*)a.dst + (size_t)b * img_bytes + out_off(m, aH, aW, y, x);
                 if constexpr (sizeof(T) == 4) {
                     *reinterpret_cast<float4*>(o) = make_float4(v[0], v[1], v[2], v[3]);
                 } else {
@@ -574,7 +587,8 @@ __global__ __launch_bounds__(256, 2) void conv3x3_mfma_kernel(const ConvArgs a)
             const bool okp = (py < pH) && (px < pW) && ((l15 & 1) == 0);
 #pragma unroll
             for (int m = 0; m < 4; ++m) {
-                T* o = (T*)a.pool_dst + (((size_t)b * pH + py) * pW + px) * a.Cout + cbase + m * 16;
+                char* o = (char*)a.pool_dst + (size_t)b * pH * pW * a.Cout * sizeof(T) +
+                          out_off(m, pH, pW, min(py, pH - 1), min(px, pW - 1));
                 if constexpr (sizeof(T) == 4) {
                     float v[4];
 #pragma unroll

@@ -9,7 +9,7 @@
 //                            (ablation path; normally fused) -- unet.py:46-54
 //   head1x1_kernel         : OutConv 1x1 + bias, NHWC in -> fp32 NCHW out (ablation path; normally
 //                            fused into the epilogue of up4.conv.double_conv.3) -- unet.py:60
-//   nhwc_to_nchw_f32_kernel: parity-test readback of an intermediate activation
+//   nhwc_to_nchw_f32_kernel: parity-test readback of an intermediate (blocked) activation as NCHW
 //   pre/postprocess kernels: model/inference.py:31-35 and :54-61 on device
 #pragma once
 #include "conv3x3_mfma.hip.h"
@@ -96,31 +96,33 @@ __global__ __launch_bounds__(256) void conv3x3_first_kernel(
             for (int j = 0; j < 4; ++j)
                 o[ct * 4 + j] = fmaxf(fmaf(acc[ct][j], sc[ct * 4 + j], sh[ct * 4 + j]), 0.f);
         if (x < W) {
-            T* op = dst + (((size_t)b * H + y) * W + x) * 64 + lc * 16;
-            constexpr int NE = Elem<T>::NE;
+            // couts lc*16 .. lc*16+15 of this pixel: half a plane record (bf16) / one plane (fp32)
+            constexpr int NE = Elem<T>::NE, PL = Elem<T>::PL;
+            char* op = (char*)dst + (size_t)b * H * W * 64 * sizeof(T) +
+                       blk_off((lc * 16) / PL, y, x, H, W) + (size_t)((lc * 16) % PL) * sizeof(T);
 #pragma unroll
-            for (int c = 0; c < 16; c += NE) *reinterpret_cast<uint4*>(op + c) = chunk_pack<T>(o + c);
+            for (int c = 0; c < 16; c += NE)
+                *reinterpret_cast<uint4*>(op + c * sizeof(T)) = chunk_pack<T>(o + c);
         }
     }
 }
 
-// thread = (output pixel, 16-byte channel chunk)
+// thread = (plane, output pixel, 16-byte chunk); blocked layout in and out
 template <typename T>
 __global__ __launch_bounds__(256) void maxpool2_kernel(const T* __restrict__ src,
                                                        T* __restrict__ dst, int B, int H, int W,
                                                        int C)  // H,W = input size
 {
-    const int Ho = H / 2, Wo = W / 2, cpp = C * (int)sizeof(T) / 16;
-    const size_t total = (size_t)B * Ho * Wo * cpp;
+    const int Ho = H / 2, Wo = W / 2, P = C / Elem<T>::PL;
+    const size_t total = (size_t)B * P * Ho * Wo * 4;
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
-        const int ch = (int)(i % cpp);
-        size_t p = i / cpp;
+        const int ch = (int)(i & 3);
+        size_t p = i >> 2;
         const int x = (int)(p % Wo); p /= Wo;
-        const int y = (int)(p % Ho);
-        const int b = (int)(p / Ho);
-        const char* s = (const char*)src + (((size_t)b * H + 2 * y) * W + 2 * x) * C * sizeof(T) + ch * 16;
-        const size_t pxb = (size_t)C * sizeof(T), rowb = (size_t)W * pxb;
-        const uint4 r = chunk_max4<T>(ldg16(s), ldg16(s + pxb), ldg16(s + rowb), ldg16(s + rowb + pxb));
+        const int y = (int)(p % Ho); p /= Ho;  // p = b * P + plane
+        const char* s = (const char*)src + (p * H + 2 * y) * (size_t)W * 64 + (size_t)(2 * x) * 64 + ch * 16;
+        const size_t rowb = (size_t)W * 64;
+        const uint4 r = chunk_max4<T>(ldg16(s), ldg16(s + 64), ldg16(s + rowb), ldg16(s + rowb + 64));
         *reinterpret_cast<uint4*>((char*)dst + i * 16) = r;
     }
 }
@@ -128,15 +130,16 @@ __global__ __launch_bounds__(256) void maxpool2_kernel(const T* __restrict__ src
 template <typename T>
 __global__ __launch_bounds__(256) void upcat_kernel(const ConvArgs a, T* __restrict__ dst)
 {
-    const int C = a.C0 + a.C1, cpp = C * (int)sizeof(T) / 16;
-    const size_t total = (size_t)a.B * a.H * a.W * cpp;
+    const int P = (a.C0 + a.C1) / Elem<T>::PL;
+    const size_t total = (size_t)a.B * P * a.H * a.W * 4;
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
-        const int cc = (int)(i % cpp);
-        size_t p = i / cpp;
+        const int ch = (int)(i & 3);
+        size_t p = i >> 2;
         const int x = (int)(p % a.W); p /= a.W;
-        const int y = (int)(p % a.H);
-        const int b = (int)(p / a.H);
-        const uint4 v = gather_chunk<T, SRC_CONCAT_UP>(a, b, y, x, cc >> 2, cc & 3);
+        const int y = (int)(p % a.H); p /= a.H;
+        const int plane = (int)(p % P);
+        const int b = (int)(p / P);
+        const uint4 v = gather_chunk<T, SRC_CONCAT_UP>(a, b, y, x, plane, ch);
         *reinterpret_cast<uint4*>((char*)dst + i * 16) = v;
     }
 }
@@ -154,11 +157,13 @@ __global__ __launch_bounds__(256) void head1x1_kernel(const T* __restrict__ src,
     if (i >= total) return;
     constexpr int NE = Elem<T>::NE;
     float acc[3] = {0.f, 0.f, 0.f};
-    const char* s = (const char*)(src + i * 64);
+    constexpr int PL = Elem<T>::PL;
+    const size_t bb = i / HW, pp = i - bb * HW;
+    const char* s = (const char*)src + bb * HW * 64 * sizeof(T) + pp * 64;  // plane 0 record
 #pragma unroll
     for (int c = 0; c < 64; c += NE) {
         float f[NE];
-        chunk_unpack<T>(ldg16(s + c * sizeof(T)), f);
+        chunk_unpack<T>(ldg16(s + (size_t)(c / PL) * HW * 64 + (c % PL) * sizeof(T)), f);
 #pragma unroll
         for (int k = 0; k < 3; ++k)
             if (k < nc) {
@@ -182,7 +187,8 @@ __global__ __launch_bounds__(256) void nhwc_to_nchw_f32_kernel(const T* __restri
         const int y = (int)(p % H); p /= H;
         const int c = (int)(p % C);
         const int b = (int)(p / C);
-        dst[i] = (float)src[(((size_t)b * H + y) * W + x) * C + c];
+        constexpr int PL = Elem<T>::PL;
+        dst[i] = (float)src[((((size_t)b * (C / PL) + c / PL) * H + y) * W + x) * PL + c % PL];
     }
 }
 
