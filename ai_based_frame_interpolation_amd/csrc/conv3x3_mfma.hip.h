@@ -70,6 +70,7 @@ struct ConvArgs {
     int tilesX, tilesY, nct;
     int relu;
     const void* zero_page; // >= 64 zero bytes: LDS-DMA source for padding pixels
+    unsigned long long* stamp;  // diagnostic builds (-DFIUNET_STAMP) only: 8 cycle sums per wave
     const float* head_w; // fused 1x1 head: [head_nc][64]
     const float* head_b; // [head_nc]
     float* head_out;     // fp32 NCHW [B][head_nc][H][W]
@@ -389,20 +390,49 @@ __global__ __launch_bounds__(256, 2) void conv3x3_mfma_kernel(const ConvArgs a)
     const int aH = a.H, aW = a.W;
     const char* const dma_src = (const char*)a.src0 + (size_t)b * a.H * a.W * a.C0 * sizeof(T);
     const char* const zero_page = (const char*)a.zero_page;
+    // The per-lane source offset of every piece is plane-invariant in the blocked layout.  Where
+    // registers allow (direct kernels without the fused head) it is computed once (NPW registers)
+    // and a plane's gather costs ~10 instructions per piece; the concat / head variants, which
+    // are at the 256-VGPR limit, recompute it per plane instead (hoisting there spilled and
+    // measured slower).
+    constexpr bool HOIST = (MODE == SRC_DIRECT && EPI != EPI_HEAD);
+    constexpr int NPW = (NPIECE + 3) / 4;
+    auto piece_off = [&](int j, int opq) __attribute__((always_inline)) {
+        const int row = j * 16 + (lane >> 2) + opq;
+        const int py = row / TWP, px = row - py * TWP;
+        const int y = y0 - 1 + py, x = x0 - 1 + px;
+        const bool ok = (px < TW + 2) & (py < THP) & (y >= 0) & (y < aH) & (x >= 0) & (x < aW);
+        // one image is < 4 GiB, so a 32-bit byte offset from the batch base is enough;
+        // ~0u marks padding (reads the zero page)
+        return ok ? (unsigned)(y * aW + x) * 64u + (((lane & 3) ^ swz(row)) << 4) : ~0u;
+    };
+    unsigned in_off[HOIST ? NPW : 1];
+    if (HOIST) {
+#pragma unroll
+        for (int jj = 0; jj < NPW; ++jj) in_off[jj] = piece_off(wave + 4 * jj, 0);
+    }
+    const unsigned plane_bytes = (unsigned)(aH * aW) * 64u;
+    const char* const zero_src = zero_page + ((lane & 3) << 4);
     auto gather_plane_dma = [&](int plane) __attribute__((always_inline)) {
-        int opq = 0;  // opaque zero: keeps the per-piece address math out of the K loop's
-        asm volatile("" : "+s"(opq));  // invariant-hoisting (it would pin ~2 VGPRs per piece)
+        const char* const base = dma_src + (size_t)plane * plane_bytes;
+        if constexpr (HOIST) {
+#pragma unroll
+            for (int jj = 0; jj < NPW; ++jj) {
+                const int j = wave + 4 * jj;
+                if (j < NPIECE) {
+                    const char* src = in_off[jj] != ~0u ? base + in_off[jj] : zero_src;
+                    glds16(src, __builtin_amdgcn_readfirstlane(lds_in_addr + (unsigned)j * 1024u));
+                }
+            }
+        } else {
+            int opq = 0;  // opaque zero: keeps the per-piece address math out of the K loop's
+            asm volatile("" : "+s"(opq));  // invariant-hoisting (it would pin a VGPR per piece)
 #pragma unroll 1
-        for (int j = wave; j < NPIECE; j += 4) {
-            const int row = j * 16 + (lane >> 2) + opq;
-            const int py = row / TWP, px = row - py * TWP;
-            const int y = y0 - 1 + py, x = x0 - 1 + px;
-            const bool ok = (px < TW + 2) & (y >= 0) & (y < aH) & (x >= 0) & (x < aW);
-            // one image is < 4 GiB, so a 32-bit byte offset from the batch base is enough
-            const unsigned off = (unsigned)((plane * aH + y) * aW + x) * 64u +
-                                 (((lane & 3) ^ swz(row)) << 4);
-            const char* src = ok ? dma_src + off : zero_page + ((lane & 3) << 4);
-            glds16(src, __builtin_amdgcn_readfirstlane(lds_in_addr + (unsigned)j * 1024u));
+            for (int j = wave; j < NPIECE; j += 4) {
+                const unsigned off = piece_off(j, opq);
+                const char* src = off != ~0u ? base + off : zero_src;
+                glds16(src, __builtin_amdgcn_readfirstlane(lds_in_addr + (unsigned)j * 1024u));
+            }
         }
     };
 
@@ -459,11 +489,22 @@ __global__ __launch_bounds__(256, 2) void conv3x3_mfma_kernel(const ConvArgs a)
         else gather_plane_up(plane, idle_slot);
     };
 
+#ifdef FIUNET_STAMP
+    // diagnostic build: where does a wave's time go?  [0] total [1] prologue [2] MFMA phases
+    // [3] end-of-step wait+barrier [4] plane-boundary gather [5] epilogue   (s_memtime ticks)
+    unsigned long long st_sum[6] = {0, 0, 0, 0, 0, 0};
+    unsigned long long st_t0 = __builtin_amdgcn_s_memtime(), st_prev = st_t0;
+#define STAMP(slot) do { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); \
+                         st_sum[slot] += t_ - st_prev; st_prev = t_; } while (0)
+#else
+#define STAMP(slot) do {} while (0)
+#endif
     // W(0) goes to slot 0, so slot 1 (+ spare) is the idle staging area for plane 0
     issue_w(0);
     gather_plane(0, 1);
     lds_dma_wait_all();
     __syncthreads();
+    STAMP(1);
 
     int step = 0;
     for (int plane = 0; plane < nplanes; ++plane) {
@@ -488,28 +529,42 @@ __global__ __launch_bounds__(256, 2) void conv3x3_mfma_kernel(const ConvArgs a)
 #pragma unroll
                     for (int n = 0; n < 8; ++n) mma_chunk<T>(acc[m][n], wa[m], xb[n]);
             }
+#ifdef FIUNET_STAMP
+            asm volatile("" :: "v"(acc[3][7][3]));  // keep the stamp behind the last MFMA
+            __builtin_amdgcn_sched_barrier(0);
+#endif
+            STAMP(2);
             if (ky == 2 && plane + 1 < nplanes) {
                 __syncthreads();  // every wave is done with this plane's in-tile and with W(step)
                 gather_plane(plane + 1, step & 1);
+                lds_dma_wait_all();
+                __syncthreads();
+                STAMP(4);
+            } else {
+                lds_dma_wait_all();   // this wave's pieces of W(step+1) landed
+                __syncthreads();      // ... and so have everyone else's
+                STAMP(3);
             }
-            lds_dma_wait_all();   // this wave's pieces of W(step+1) (and of the in-tile) landed
-            __syncthreads();      // ... and so have everyone else's; in-tile writes visible
         }
     }
 
-    // ---- epilogue: y = relu(acc * scale + shift); lane holds couts cbase+m*16+lc*4+{0..3} ----
-    const int cbase = ct * BN + wc * 64 + lc * 4;
-    // blocked output: cout c lives in plane c / PL at byte (c % PL) * sizeof(T) of the pixel record
-    const size_t img_bytes = (size_t)aH * aW * a.Cout * sizeof(T);
-    auto out_off = [&](int m, int hh, int ww, int y, int x) __attribute__((always_inline)) {
-        const int c = cbase + m * 16;
-        return blk_off(c / PL, y, x, hh, ww) + (size_t)(c % PL) * sizeof(T);
+    // ---- epilogue: y = relu(acc * scale + shift) -> blocked activation records -------------------
+    // Which couts a lane holds: accumulator tile m, register j of lane group lc is MFMA row
+    // lc*4+j of that tile.  fp32: row r of tile m <-> cout m*16+r, so a lane's 4 registers are one
+    // 16-B quarter of the tile's 64-B plane record.  bf16: the packed weight rows are permuted on
+    // the host (fiunet.hip, `bf16_row_to_cout`) so that tiles 2g and 2g+1 together give the lane
+    // the 8 consecutive couts g*32+lc*8 .. +7: ONE 16-B store per lane and tile pair, and the 4
+    // lane groups of a pixel write its whole 64-B record (1 KiB contiguous per store instruction).
+    constexpr bool PERM = sizeof(T) == 2;
+    const int wbase_c = ct * BN + wc * 64;  // first cout of this wave
+    auto cofs = [&](int m) __attribute__((always_inline)) {  // cout (within the wave) of register j=0
+        return PERM ? (m >> 1) * 32 + lc * 8 + (m & 1) * 4 : m * 16 + lc * 4;
     };
     float4 sc[4], sh[4];
 #pragma unroll
     for (int m = 0; m < 4; ++m) {
-        sc[m] = *reinterpret_cast<const float4*>(a.scale + cbase + m * 16);
-        sh[m] = *reinterpret_cast<const float4*>(a.shift + cbase + m * 16);
+        sc[m] = *reinterpret_cast<const float4*>(a.scale + wbase_c + cofs(m));
+        sh[m] = *reinterpret_cast<const float4*>(a.shift + wbase_c + cofs(m));
     }
     float hw[3][4][4];
     if (EPI == EPI_HEAD) {
@@ -518,48 +573,64 @@ __global__ __launch_bounds__(256, 2) void conv3x3_mfma_kernel(const ConvArgs a)
 #pragma unroll
             for (int m = 0; m < 4; ++m) {
                 const float4 v = c < a.head_nc
-                    ? *reinterpret_cast<const float4*>(a.head_w + c * 64 + lc * 4 + m * 16)
+                    ? *reinterpret_cast<const float4*>(a.head_w + c * 64 + cofs(m))
                     : make_float4(0.f, 0.f, 0.f, 0.f);
                 hw[c][m][0] = v.x; hw[c][m][1] = v.y; hw[c][m][2] = v.z; hw[c][m][3] = v.w;
             }
     }
+    // record address = image base + plane * plane_stride + pixel * 64 + byte within the record
+    const size_t plane_stride = (size_t)aH * aW * 64;
+    const int plane0 = wbase_c / PL;                       // first output plane of this wave
+    const int rec_byte = PERM ? lc * 16 : lc * 16;         // this lane's 16 B of a 64-B record
+    char* const out_img = a.dst ? (char*)a.dst + (size_t)b * plane_stride * (a.Cout / PL) +
+                                  (size_t)plane0 * plane_stride + rec_byte : nullptr;
     const int pH = aH >> 1, pW = aW >> 1;  // EPI_POOL: MaxPool2d(2) output size (floor)
+    const size_t pplane_stride = (size_t)pH * pW * 64;
+    char* const pool_img = EPI == EPI_POOL ? (char*)a.pool_dst + (size_t)b * pplane_stride * (a.Cout / PL) +
+                                             (size_t)plane0 * pplane_stride + rec_byte : nullptr;
 #pragma unroll
     for (int n = 0; n < 8; ++n) {
         const int y = y0 + wp * ROWS_W + n / FR;
         const int x = x0 + (n % FR) * 16 + l15;
         const bool ok = (y < aH) && (x < aW);
         float hsum[3] = {0.f, 0.f, 0.f};
+        float v[4][4];
 #pragma unroll
         for (int m = 0; m < 4; ++m) {
-            float v[4];
-            v[0] = fmaf(acc[m][n][0], sc[m].x, sh[m].x);
-            v[1] = fmaf(acc[m][n][1], sc[m].y, sh[m].y);
-            v[2] = fmaf(acc[m][n][2], sc[m].z, sh[m].z);
-            v[3] = fmaf(acc[m][n][3], sc[m].w, sh[m].w);
+            v[m][0] = fmaf(acc[m][n][0], sc[m].x, sh[m].x);
+            v[m][1] = fmaf(acc[m][n][1], sc[m].y, sh[m].y);
+            v[m][2] = fmaf(acc[m][n][2], sc[m].z, sh[m].z);
+            v[m][3] = fmaf(acc[m][n][3], sc[m].w, sh[m].w);
             if (a.relu) {
 #pragma unroll
-                for (int j = 0; j < 4; ++j) v[j] = fmaxf(v[j], 0.f);
+                for (int j = 0; j < 4; ++j) v[m][j] = fmaxf(v[m][j], 0.f);
             }
             if (EPI == EPI_HEAD) {
 #pragma unroll
                 for (int c = 0; c < 3; ++c)
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) hsum[c] = fmaf(v[j], hw[c][m][j], hsum[c]);
-            }
-            if (ok && a.dst) {
-                char* o = (char*)a.dst + (size_t)b * img_bytes + out_off(m, aH, aW, y, x);
-                if constexpr (sizeof(T) == 4) {
-                    *reinterpret_cast<float4*>(o) = make_float4(v[0], v[1], v[2], v[3]);
-                } else {
-                    *reinterpret_cast<uint2*>(o) =
-                        make_uint2(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]));
-                }
+                    for (int j = 0; j < 4; ++j) hsum[c] = fmaf(v[m][j], hw[c][m][j], hsum[c]);
             }
             if (EPI == EPI_POOL) {
                 // keep the post-activation values in acc: the 2x2 max below needs the row pair
 #pragma unroll
-                for (int j = 0; j < 4; ++j) acc[m][n][j] = v[j];
+                for (int j = 0; j < 4; ++j) acc[m][n][j] = v[m][j];
+            }
+        }
+        if (ok && out_img) {
+            char* o = out_img + (size_t)(y * aW + x) * 64;
+            if constexpr (PERM) {
+#pragma unroll
+                for (int g = 0; g < 2; ++g)
+                    *reinterpret_cast<uint4*>(o + g * plane_stride) = make_uint4(
+                        pack_bf16x2(v[2 * g][0], v[2 * g][1]), pack_bf16x2(v[2 * g][2], v[2 * g][3]),
+                        pack_bf16x2(v[2 * g + 1][0], v[2 * g + 1][1]),
+                        pack_bf16x2(v[2 * g + 1][2], v[2 * g + 1][3]));
+            } else {
+#pragma unroll
+                for (int m = 0; m < 4; ++m)
+                    *reinterpret_cast<float4*>(o + m * plane_stride) =
+                        make_float4(v[m][0], v[m][1], v[m][2], v[m][3]);
             }
         }
         if (EPI == EPI_HEAD) {
@@ -575,8 +646,8 @@ __global__ __launch_bounds__(256, 2) void conv3x3_mfma_kernel(const ConvArgs a)
     }
     if (EPI == EPI_POOL) {
         // MaxPool2d(2) of this conv's output (unet.py:28), fused here so the consumer conv reads a
-        // ready NHWC tensor by LDS-DMA: tile origins are even, a wave owns whole row pairs
-        // (fragments n and n+FR) and the column partner is the neighbouring lane (l15 ^ 1).
+        // ready tensor by LDS-DMA: tile origins are even, a wave owns whole row pairs (fragments n
+        // and n+FR) and the column partner is the neighbouring lane (l15 ^ 1).
         // max(round(a), round(b)) == round(max(a, b)), so this equals pooling the stored tensor.
 #pragma unroll
         for (int n = 0; n < 8; ++n) {
@@ -585,31 +656,48 @@ __global__ __launch_bounds__(256, 2) void conv3x3_mfma_kernel(const ConvArgs a)
             const int x = x0 + (n % FR) * 16 + l15;
             const int py = y >> 1, px = x >> 1;
             const bool okp = (py < pH) && (px < pW) && ((l15 & 1) == 0);
+            char* o = pool_img + (size_t)(min(py, pH - 1) * pW + min(px, pW - 1)) * 64;
+            if constexpr (!PERM) {
 #pragma unroll
-            for (int m = 0; m < 4; ++m) {
-                char* o = (char*)a.pool_dst + (size_t)b * pH * pW * a.Cout * sizeof(T) +
-                          out_off(m, pH, pW, min(py, pH - 1), min(px, pW - 1));
-                if constexpr (sizeof(T) == 4) {
-                    float v[4];
+                for (int m = 0; m < 4; ++m) {
+                    float r[4];
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
                         const float cm = fmaxf(acc[m][n][j], acc[m][n + FR][j]);
-                        v[j] = fmaxf(cm, __uint_as_float(dpp_swap_pairs(__float_as_uint(cm))));
+                        r[j] = fmaxf(cm, __uint_as_float(dpp_swap_pairs(__float_as_uint(cm))));
                     }
-                    if (okp) *reinterpret_cast<float4*>(o) = make_float4(v[0], v[1], v[2], v[3]);
-                } else {
-                    // values are >= 0 (post-ReLU): packed int16 max on the rounded bf16 pairs
-                    const unsigned a0 = pk_max_i16(pack_bf16x2(acc[m][n][0], acc[m][n][1]),
-                                                   pack_bf16x2(acc[m][n + FR][0], acc[m][n + FR][1]));
-                    const unsigned a1 = pk_max_i16(pack_bf16x2(acc[m][n][2], acc[m][n][3]),
-                                                   pack_bf16x2(acc[m][n + FR][2], acc[m][n + FR][3]));
-                    const unsigned r0 = pk_max_i16(a0, dpp_swap_pairs(a0));
-                    const unsigned r1 = pk_max_i16(a1, dpp_swap_pairs(a1));
-                    if (okp) *reinterpret_cast<uint2*>(o) = make_uint2(r0, r1);
+                    if (okp) *reinterpret_cast<float4*>(o + m * pplane_stride) = make_float4(r[0], r[1], r[2], r[3]);
+                }
+            } else {
+                // values are >= 0 (post-ReLU): packed int16 max on the rounded bf16 pairs
+#pragma unroll
+                for (int g = 0; g < 2; ++g) {
+                    unsigned r[4];
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) {
+                        const int m = 2 * g + h;
+                        const unsigned a0 = pk_max_i16(pack_bf16x2(acc[m][n][0], acc[m][n][1]),
+                                                       pack_bf16x2(acc[m][n + FR][0], acc[m][n + FR][1]));
+                        const unsigned a1 = pk_max_i16(pack_bf16x2(acc[m][n][2], acc[m][n][3]),
+                                                       pack_bf16x2(acc[m][n + FR][2], acc[m][n + FR][3]));
+                        r[2 * h] = pk_max_i16(a0, dpp_swap_pairs(a0));
+                        r[2 * h + 1] = pk_max_i16(a1, dpp_swap_pairs(a1));
+                    }
+                    if (okp) *reinterpret_cast<uint4*>(o + g * pplane_stride) = make_uint4(r[0], r[1], r[2], r[3]);
                 }
             }
         }
     }
+#ifdef FIUNET_STAMP
+    STAMP(5);
+    st_sum[0] = st_prev - st_t0;
+    if (a.stamp && lane == 0) {  // one private 64-B record per wave: no atomics, no contention
+        unsigned long long* rec = a.stamp + ((size_t)blockIdx.x * 4 + wave) * 8;
+#pragma unroll
+        for (int k = 0; k < 6; ++k) rec[k] = st_sum[k];
+        rec[6] = 1ull;
+    }
+#endif
 }
 
 }  // namespace fiunet

@@ -38,6 +38,7 @@ int fail(int code, const std::string& msg)
     } while (0)
 
 constexpr int NCONV = 18;
+constexpr size_t kStampWaves = 4 * 40000;  // diagnostic stamp records
 // conv index = 2*block + {0,1}; blocks: inc, down1..4, up1..4 (state-dict order)
 const char* const kBlockPrefix[9] = {
     "unet.inc", "unet.down1.maxpool_conv.1", "unet.down2.maxpool_conv.1",
@@ -65,6 +66,14 @@ struct ConvWeights {
     float* scale = nullptr;
     float* shift = nullptr;
 };
+
+// bf16 kernels: packed weight row R (= MFMA A row within its 32-cout group) holds this cout, so
+// that accumulator tiles 2g and 2g+1 give a lane 8 consecutive couts (conv3x3_mfma.hip.h epilogue)
+inline int bf16_row_to_cout(int R)
+{
+    const int r = R & 15;
+    return (R & ~31) + (r >> 2) * 8 + ((R >> 4) & 1) * 4 + (r & 3);
+}
 
 uint16_t f32_to_bf16_rne(float f)
 {
@@ -117,6 +126,8 @@ struct fiunet_ctx {
     float* head_w = nullptr;  // [cf][64]
     float* head_b = nullptr;  // [cf]
     void* zero_page = nullptr;  // 256 zero bytes (LDS-DMA source for conv padding)
+    unsigned long long* stamps = nullptr;  // per-wave cycle records (diagnostic -DFIUNET_STAMP builds)
+    int stamp_layer = -1;
     std::vector<void*> owned;
     // per-layer HIP-event profiling (fiunet_profile_*): NCONV+1 events per recorded forward
     bool profiling = false;
@@ -261,6 +272,7 @@ int forward_impl(fiunet_ctx* ctx, const float* f1, const float* f2, float* out, 
         a.scale = cw.scale; a.shift = cw.shift;
         a.relu = 1;
         a.zero_page = ctx->zero_page;
+        a.stamp = (ctx->stamps && i == ctx->stamp_layer) ? ctx->stamps : nullptr;
         a.dst = act(i);
         int mode = kMode[i];
         a.src0 = act(kSrc0[i]);
@@ -429,13 +441,16 @@ int fiunet_load_weights(fiunet_ctx* ctx, int n, const char* const* names,
         const size_t nel = (size_t)cout * cin * 9;
         std::vector<float> p32(nel);
         std::vector<uint16_t> p16(nel);
-        for (int co = 0; co < cout; ++co)
+        for (int R = 0; R < cout; ++R) {  // R = packed row; fp32 rows are in natural cout order
+            const int co16 = bf16_row_to_cout(R);
             for (int ci = 0; ci < cin; ++ci)
                 for (int t = 0; t < 9; ++t) {
-                    const float v = w[((size_t)co * cin + ci) * 9 + t];
-                    p32[(((size_t)(ci / 16) * 9 + t) * cout + co) * 16 + (ci % 16)] = v;
-                    p16[(((size_t)(ci / 32) * 9 + t) * cout + co) * 32 + (ci % 32)] = f32_to_bf16_rne(v);
+                    p32[(((size_t)(ci / 16) * 9 + t) * cout + R) * 16 + (ci % 16)] =
+                        w[((size_t)R * cin + ci) * 9 + t];
+                    p16[(((size_t)(ci / 32) * 9 + t) * cout + R) * 32 + (ci % 32)] =
+                        f32_to_bf16_rne(w[((size_t)co16 * cin + ci) * 9 + t]);
                 }
+        }
         if ((rc = dev_upload(ctx, p32.data(), nel * 4, &cw.w_f32))) return rc;
         if ((rc = dev_upload(ctx, p16.data(), nel * 2, &cw.w_bf16))) return rc;
     }
@@ -448,6 +463,15 @@ int fiunet_load_weights(fiunet_ctx* ctx, int n, const char* const* names,
         if ((rc = dev_upload(ctx, bi, (size_t)ctx->cf * 4, (void**)&ctx->head_b))) return rc;
         const std::vector<char> zeros(256, 0);
         if ((rc = dev_upload(ctx, zeros.data(), zeros.size(), &ctx->zero_page))) return rc;
+#ifdef FIUNET_STAMP
+        {   // one 64-B record per wave of the largest launch (B=8 1080p: 32 640 workgroups)
+            void* d = nullptr;
+            HIP_TRY(hipMalloc(&d, kStampWaves * 64));
+            ctx->owned.push_back(d);
+            HIP_TRY(hipMemset(d, 0, kStampWaves * 64));
+            ctx->stamps = (unsigned long long*)d;
+        }
+#endif
     }
     ctx->loaded = true;
     return FIUNET_OK;
@@ -531,6 +555,27 @@ int fiunet_postprocess_u8(const float* in, uint8_t* out, size_t n, void* stream)
     HIP_TRY(hipGetLastError());
     return FIUNET_OK;
 }
+
+#ifdef FIUNET_STAMP
+// diagnostic builds only (not part of the ABI): stamp ONE stage per forward; read = sums over waves
+int fiunet_debug_stamp_layer(fiunet_ctx* ctx, int layer)
+{
+    ctx->stamp_layer = layer;
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemset(ctx->stamps, 0, kStampWaves * 64));
+    return FIUNET_OK;
+}
+int fiunet_debug_stamps(fiunet_ctx* ctx, unsigned long long* out /* [8] */)
+{
+    HIP_TRY(hipDeviceSynchronize());
+    std::vector<unsigned long long> h(kStampWaves * 8);
+    HIP_TRY(hipMemcpy(h.data(), ctx->stamps, kStampWaves * 64, hipMemcpyDeviceToHost));
+    for (int k = 0; k < 8; ++k) out[k] = 0;
+    for (size_t w = 0; w < kStampWaves; ++w)
+        for (int k = 0; k < 8; ++k) out[k] += h[w * 8 + k];
+    return FIUNET_OK;
+}
+#endif
 
 int fiunet_profile_enable(fiunet_ctx* ctx, int enable)
 {

@@ -87,7 +87,7 @@ def main():
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N > 1")
     dist = None
-    if world > 1:
+    if world > 1 or "RANK" in os.environ:  # under torch.distributed.run (also with one rank)
         import torch.distributed as dist
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local_rank}"))
