@@ -277,7 +277,7 @@ __device__ __forceinline__ void mma_chunk<float>(f32x4& acc, const uint4& wa, co
     acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(wa.w), __uint_as_float(xb.w), acc, 0, 0, 0);
 }
 
-enum Epilogue { EPI_PLAIN = 0, EPI_HEAD = 1, EPI_POOL = 2 };
+enum Epilogue { EPI_PLAIN = 0, EPI_HEAD = 1 /* 1x1 head, 1 class */, EPI_POOL = 2, EPI_HEAD3 = 3 /* 3 classes */ };
 
 // value of the neighbouring lane (lane ^ 1) through DPP quad_perm [1,0,3,2]: no LDS crossbar
 __device__ __forceinline__ unsigned dpp_swap_pairs(unsigned v)
@@ -316,7 +316,8 @@ __global__ __launch_bounds__(256, 2) void conv3x3_mfma_kernel(const ConvArgs a)
     constexpr int FR = TW / 16;       // 16-pixel fragments per tile row
     constexpr int ROWS_W = 8 / FR;    // tile rows per wave
     static_assert(TH == ROWS_W * WAVES_P, "wave tile must be 64 couts x 128 pixels");
-    static_assert(EPI != EPI_HEAD || BN == 64, "fused head needs all 64 couts in one wave");
+    constexpr int HNC = EPI == EPI_HEAD ? 1 : (EPI == EPI_HEAD3 ? 3 : 0);  // fused-head classes
+    static_assert(HNC == 0 || BN == 64, "fused head needs all 64 couts in one wave");
     static_assert(MODE == SRC_DIRECT || MODE == SRC_CONCAT_UP, "pooling is fused into the producer");
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -395,7 +396,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_mfma_kernel(const ConvArgs a)
     // and a plane's gather costs ~10 instructions per piece; the concat / head variants, which
     // are at the 256-VGPR limit, recompute it per plane instead (hoisting there spilled and
     // measured slower).
-    constexpr bool HOIST = (MODE == SRC_DIRECT && EPI != EPI_HEAD);
+    constexpr bool HOIST = (MODE == SRC_DIRECT && HNC == 0);
     constexpr int NPW = (NPIECE + 3) / 4;
     auto piece_off = [&](int j, int opq) __attribute__((always_inline)) {
         const int row = j * 16 + (lane >> 2) + opq;
@@ -566,18 +567,14 @@ __global__ __launch_bounds__(256, 2) void conv3x3_mfma_kernel(const ConvArgs a)
         sc[m] = *reinterpret_cast<const float4*>(a.scale + wbase_c + cofs(m));
         sh[m] = *reinterpret_cast<const float4*>(a.shift + wbase_c + cofs(m));
     }
-    float hw[3][4][4];
-    if (EPI == EPI_HEAD) {
+    float hw[HNC > 0 ? HNC : 1][4][4];
 #pragma unroll
-        for (int c = 0; c < 3; ++c)
+    for (int c = 0; c < HNC; ++c)
 #pragma unroll
-            for (int m = 0; m < 4; ++m) {
-                const float4 v = c < a.head_nc
-                    ? *reinterpret_cast<const float4*>(a.head_w + c * 64 + cofs(m))
-                    : make_float4(0.f, 0.f, 0.f, 0.f);
-                hw[c][m][0] = v.x; hw[c][m][1] = v.y; hw[c][m][2] = v.z; hw[c][m][3] = v.w;
-            }
-    }
+        for (int m = 0; m < 4; ++m) {
+            const float4 v = *reinterpret_cast<const float4*>(a.head_w + c * 64 + cofs(m));
+            hw[c][m][0] = v.x; hw[c][m][1] = v.y; hw[c][m][2] = v.z; hw[c][m][3] = v.w;
+        }
     // record address = image base + plane * plane_stride + pixel * 64 + byte within the record
     const size_t plane_stride = (size_t)aH * aW * 64;
     const int plane0 = wbase_c / PL;                       // first output plane of this wave
@@ -593,7 +590,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_mfma_kernel(const ConvArgs a)
         const int y = y0 + wp * ROWS_W + n / FR;
         const int x = x0 + (n % FR) * 16 + l15;
         const bool ok = (y < aH) && (x < aW);
-        float hsum[3] = {0.f, 0.f, 0.f};
+        float hsum[HNC > 0 ? HNC : 1] = {};
         float v[4][4];
 #pragma unroll
         for (int m = 0; m < 4; ++m) {
@@ -605,12 +602,10 @@ __global__ __launch_bounds__(256, 2) void conv3x3_mfma_kernel(const ConvArgs a)
 #pragma unroll
                 for (int j = 0; j < 4; ++j) v[m][j] = fmaxf(v[m][j], 0.f);
             }
-            if (EPI == EPI_HEAD) {
 #pragma unroll
-                for (int c = 0; c < 3; ++c)
+            for (int c = 0; c < HNC; ++c)
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) hsum[c] = fmaf(v[m][j], hw[c][m][j], hsum[c]);
-            }
+                for (int j = 0; j < 4; ++j) hsum[c] = fmaf(v[m][j], hw[c][m][j], hsum[c]);
             if (EPI == EPI_POOL) {
                 // keep the post-activation values in acc: the 2x2 max below needs the row pair
 #pragma unroll
@@ -633,15 +628,13 @@ __global__ __launch_bounds__(256, 2) void conv3x3_mfma_kernel(const ConvArgs a)
                         make_float4(v[m][0], v[m][1], v[m][2], v[m][3]);
             }
         }
-        if (EPI == EPI_HEAD) {
 #pragma unroll
-            for (int c = 0; c < 3; ++c) {
-                float s = hsum[c];
-                s += __shfl_xor(s, 16);
-                s += __shfl_xor(s, 32);
-                if (c < a.head_nc && ok && lc == 0)
-                    a.head_out[(((size_t)b * a.head_nc + c) * aH + y) * aW + x] = s + a.head_b[c];
-            }
+        for (int c = 0; c < HNC; ++c) {
+            float s = hsum[c];
+            s += __shfl_xor(s, 16);
+            s += __shfl_xor(s, 32);
+            if (ok && lc == 0)
+                a.head_out[(((size_t)b * HNC + c) * aH + y) * aW + x] = s + a.head_b[c];
         }
     }
     if (EPI == EPI_POOL) {

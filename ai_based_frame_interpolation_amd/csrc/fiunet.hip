@@ -198,7 +198,7 @@ template <typename T, int MODE, int EPI> int launch_conv_shape(const ConvArgs& a
         return wide ? launch_conv_cfg<T, 64, 16, 32, MODE, EPI>(a, s)
                     : launch_conv_cfg<T, 64, 32, 16, MODE, EPI>(a, s);
     }
-    if constexpr (EPI != EPI_HEAD) {
+    if constexpr (EPI != EPI_HEAD && EPI != EPI_HEAD3) {
         if (a.Cout % 128 != 0) return fail(FIUNET_ERR_INVALID_ARG, "Cout must be 64 or k*128");
         const bool wide = padded_area(a.H, a.W, 8, 32) <= padded_area(a.H, a.W, 16, 16);
         return wide ? launch_conv_cfg<T, 128, 8, 32, MODE, EPI>(a, s)
@@ -207,7 +207,7 @@ template <typename T, int MODE, int EPI> int launch_conv_shape(const ConvArgs& a
     return fail(FIUNET_ERR_INVALID_ARG, "fused head needs Cout == 64");
 }
 
-// mode: SRC_DIRECT | SRC_CONCAT_UP; epi: EPI_PLAIN | EPI_HEAD | EPI_POOL (direct sources only)
+// mode: SRC_DIRECT | SRC_CONCAT_UP; epi: EPI_PLAIN | EPI_HEAD | EPI_HEAD3 | EPI_POOL (direct sources only)
 template <typename T> int launch_conv(const ConvArgs& a, int mode, int epi, hipStream_t s)
 {
     constexpr int PL = Elem<T>::PL;
@@ -215,6 +215,7 @@ template <typename T> int launch_conv(const ConvArgs& a, int mode, int epi, hipS
     if (mode == SRC_CONCAT_UP && epi == EPI_PLAIN) return launch_conv_shape<T, SRC_CONCAT_UP, EPI_PLAIN>(a, s);
     if (mode == SRC_DIRECT && epi == EPI_PLAIN) return launch_conv_shape<T, SRC_DIRECT, EPI_PLAIN>(a, s);
     if (mode == SRC_DIRECT && epi == EPI_HEAD) return launch_conv_shape<T, SRC_DIRECT, EPI_HEAD>(a, s);
+    if (mode == SRC_DIRECT && epi == EPI_HEAD3) return launch_conv_shape<T, SRC_DIRECT, EPI_HEAD3>(a, s);
     if (mode == SRC_DIRECT && epi == EPI_POOL) return launch_conv_shape<T, SRC_DIRECT, EPI_POOL>(a, s);
     return fail(FIUNET_ERR_INVALID_ARG, "unsupported gather/epilogue combination");
 }
@@ -245,8 +246,8 @@ int forward_impl(fiunet_ctx* ctx, const float* f1, const float* f2, float* out, 
     // conv 0: fp32 stem (unet.py:72, first conv of inc)
     {
         const ConvWeights& cw = ctx->conv[0];
-        const long long ntiles = (long long)B * H * ((W + 15) / 16);
-        dim3 grid((unsigned)std::min<long long>((ntiles + 3) / 4, 256 * 64));
+        const long long nruns = (long long)B * H * (((W + 15) / 16 + 7) / 8);  // 8-tile row runs
+        dim3 grid((unsigned)std::min<long long>((nruns + 3) / 4, 256 * 64));
         if (ctx->cf == 1)
             hipLaunchKernelGGL((conv3x3_first_kernel<T, 1>), grid, dim3(256), 0, s, f1, f2,
                                (const float*)cw.w_f32, cw.scale, cw.shift, act(0), B, H, W);
@@ -312,7 +313,7 @@ int forward_impl(fiunet_ctx* ctx, const float* f1, const float* f2, float* out, 
             a.pool_dst = ws + p.pool_off[kPoolOut[i]];
         }
         if (i == NCONV - 1 && !unfused) {  // fuse OutConv (unet.py:60) into the last epilogue
-            epi = EPI_HEAD;
+            epi = ctx->cf == 1 ? EPI_HEAD : EPI_HEAD3;
             a.head_w = ctx->head_w; a.head_b = ctx->head_b; a.head_out = out; a.head_nc = ctx->cf;
             if (!(ctx->flags & FIUNET_OPT_KEEP_ALL)) a.dst = nullptr;
         }

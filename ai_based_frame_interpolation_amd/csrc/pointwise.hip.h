@@ -49,60 +49,71 @@ __global__ __launch_bounds__(256) void conv3x3_first_kernel(
 #pragma unroll
     for (int c = 0; c < 16; ++c) { sc[c] = scale[lc * 16 + c]; sh[c] = shift[lc * 16 + c]; }
 
-    const int tilesX = (W + 15) / 16;
-    const long long ntiles = (long long)B * H * tilesX;
+    // work unit = a run of RUN consecutive 16-pixel tiles of one image row: (b, y) and the row
+    // validity of every tap are fixed for the run, only x advances, so the per-tile address work is
+    // one add per k-group; the loads of tile i+1 are issued before the MFMAs of tile i.
+    constexpr int RUN = 8;
+    const int tilesX = (W + 15) / 16, runsX = (tilesX + RUN - 1) / RUN;
+    const long long nruns = (long long)B * H * runsX;
     const size_t plane = (size_t)H * W;
-    auto load_tile = [&](long long t, float* v) __attribute__((always_inline)) {
-        const int xt = (int)(t % tilesX);
-        const long long r = t / tilesX;
+    for (long long rix = (long long)blockIdx.x * 4 + wave; rix < nruns; rix += (long long)gridDim.x * 4) {
+        const int rx = (int)(rix % runsX);
+        const long long r = rix / runsX;
         const int y = (int)(r % H), b = (int)(r / H);
-        const int x = xt * 16 + l15;
+        const int xt0 = rx * RUN, xt1 = min(xt0 + RUN, tilesX);
+        const float* p[KG];   // address of this lane's tap/channel for pixel x = xt0*16 + l15
+        int dxs[KG];          // its dx - 1, or a value that fails every x check when the row/k is invalid
 #pragma unroll
         for (int g = 0; g < KG; ++g) {
             const int ko = koff[g];
-            const int yy = y + (ko & 3) - 1, xx = x + ((ko >> 2) & 3) - 1, ci = ko >> 4;
-            const bool ok = ko >= 0 && yy >= 0 && yy < H && xx >= 0 && xx < W;
+            const int yy = y + (ko & 3) - 1, ci = ko >> 4;
+            const bool rowok = ko >= 0 && yy >= 0 && yy < H;
             // channel order of cat([frame1, frame2], dim=1)  (unet.py:109)
             const float* src = ci < CF ? f1 : f2;
             const int cc = ci < CF ? ci : ci - CF;
-            v[g] = ok ? src[((size_t)b * CF + cc) * plane + (size_t)yy * W + xx] : 0.f;
+            dxs[g] = rowok ? ((ko >> 2) & 3) - 1 : -(1 << 28);
+            p[g] = src + ((size_t)b * CF + (rowok ? cc : 0)) * plane + (size_t)(rowok ? yy : 0) * W +
+                   (xt0 * 16 + l15);
         }
-    };
-    const long long tstep = (long long)gridDim.x * 4;
-    long long t = (long long)blockIdx.x * 4 + wave;
-    float vn[KG];
-    if (t < ntiles) load_tile(t, vn);
-    for (; t < ntiles; t += tstep) {
-        float v[KG];
+        auto load_tile = [&](int xt, float* v) __attribute__((always_inline)) {
+            const int x = xt * 16 + l15;
 #pragma unroll
-        for (int g = 0; g < KG; ++g) v[g] = vn[g];
-        if (t + tstep < ntiles) load_tile(t + tstep, vn);  // prefetch: hides the load latency
-        const int xt = (int)(t % tilesX);
-        const long long r = t / tilesX;
-        const int y = (int)(r % H), b = (int)(r / H);
-        const int x = xt * 16 + l15;
-        f32x4 acc[4];
+            for (int g = 0; g < KG; ++g) {
+                const int xx = x + dxs[g];
+                v[g] = (xx >= 0 && xx < W) ? p[g][(xt - xt0) * 16 + dxs[g]] : 0.f;
+            }
+        };
+        float vn[KG];
+        load_tile(xt0, vn);
+        for (int xt = xt0; xt < xt1; ++xt) {
+            float v[KG];
 #pragma unroll
-        for (int ct = 0; ct < 4; ++ct) acc[ct] = f32x4{0.f, 0.f, 0.f, 0.f};
+            for (int g = 0; g < KG; ++g) v[g] = vn[g];
+            if (xt + 1 < xt1) load_tile(xt + 1, vn);
+            const int x = xt * 16 + l15;
+            f32x4 acc[4];
 #pragma unroll
-        for (int g = 0; g < KG; ++g)
+            for (int ct = 0; ct < 4; ++ct) acc[ct] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int g = 0; g < KG; ++g)
+#pragma unroll
+                for (int ct = 0; ct < 4; ++ct)
+                    acc[ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[ct][g], v[g], acc[ct], 0, 0, 0);
+            float o[16];
 #pragma unroll
             for (int ct = 0; ct < 4; ++ct)
-                acc[ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[ct][g], v[g], acc[ct], 0, 0, 0);
-        float o[16];
 #pragma unroll
-        for (int ct = 0; ct < 4; ++ct)
+                for (int j = 0; j < 4; ++j)
+                    o[ct * 4 + j] = fmaxf(fmaf(acc[ct][j], sc[ct * 4 + j], sh[ct * 4 + j]), 0.f);
+            if (x < W) {
+                // couts lc*16 .. lc*16+15 of this pixel: half a plane record (bf16) / one plane (fp32)
+                constexpr int NE = Elem<T>::NE, PL = Elem<T>::PL;
+                char* op = (char*)dst + (size_t)b * H * W * 64 * sizeof(T) +
+                           blk_off((lc * 16) / PL, y, x, H, W) + (size_t)((lc * 16) % PL) * sizeof(T);
 #pragma unroll
-            for (int j = 0; j < 4; ++j)
-                o[ct * 4 + j] = fmaxf(fmaf(acc[ct][j], sc[ct * 4 + j], sh[ct * 4 + j]), 0.f);
-        if (x < W) {
-            // couts lc*16 .. lc*16+15 of this pixel: half a plane record (bf16) / one plane (fp32)
-            constexpr int NE = Elem<T>::NE, PL = Elem<T>::PL;
-            char* op = (char*)dst + (size_t)b * H * W * 64 * sizeof(T) +
-                       blk_off((lc * 16) / PL, y, x, H, W) + (size_t)((lc * 16) % PL) * sizeof(T);
-#pragma unroll
-            for (int c = 0; c < 16; c += NE)
-                *reinterpret_cast<uint4*>(op + c * sizeof(T)) = chunk_pack<T>(o + c);
+                for (int c = 0; c < 16; c += NE)
+                    *reinterpret_cast<uint4*>(op + c * sizeof(T)) = chunk_pack<T>(o + c);
+            }
         }
     }
 }
