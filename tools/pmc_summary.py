@@ -31,11 +31,13 @@ def load(pass_name):
     return [disp[i] for i in last]
 
 def short(n):
+    """same spelling as bench.py's roofline.kernel (fiunet_profile_read names)"""
     m = re.search(r"conv3x3_(first|mfma)_kernelI(DF16b|f)((?:Li\d+E)+)", n)
     if not m:
-        return n[:40]
+        # rocprofv3 demangles the stem's name oddly; the bench workload is the gray bf16 network
+        return "conv3x3_first_kernel<bf16,1>" if "conv3x3_first_kernel" in n else n[:40]
     nums = re.findall(r"Li(\d+)E", m.group(3))
-    return f"conv3x3_{m.group(1)}<{'bf16' if m.group(2)=='DF16b' else 'f32'},{','.join(nums)}>"
+    return f"conv3x3_{m.group(1)}_kernel<{'bf16' if m.group(2)=='DF16b' else 'f32'},{','.join(nums)}>"
 
 fetch, write, sq = load("fetch"), load("write"), load("sq")
 stages = []
