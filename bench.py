@@ -163,7 +163,8 @@ def main():
     achieved = dom["flops"] / (dom["ms"] * 1e-3) / 1e12 if dom["ms"] > 0 else 0.0
     traffic = None
     pmc = os.path.join(ROOT, "profiles", "pmc_summary.json")
-    if os.path.exists(pmc):
+    default_workload = (b, h, w, args.precision, args.unfused) == (8, 1080, 1920, "bf16", False)
+    if os.path.exists(pmc) and default_workload:  # the committed PMC pass is of this workload only
         try:
             traffic = json.load(open(pmc)).get(dom_name, {}).get("hbm_bytes_per_launch")
         except Exception:
