@@ -41,7 +41,8 @@ namespace fiunet {
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 
-enum SrcMode { SRC_DIRECT = 0, SRC_POOL = 1 /* host-side tag only */, SRC_CONCAT_UP = 2 };
+enum SrcMode { SRC_DIRECT = 0, SRC_POOL = 1 /* host-side tag only */, SRC_CONCAT_UP = 2,
+               SRC_STEM = 3 /* input = stem conv of the raw frame pair, computed in the gather */ };
 
 // Activation layout in HBM: plane-major blocked channels-last, [B][C/PL][H][W][PL] with one
 // 64-byte "plane" record per pixel (PL = 32 bf16 / 16 fp32 channels).  A tile row of one plane is
@@ -70,6 +71,13 @@ struct ConvArgs {
     int tilesX, tilesY, nct;
     int relu;
     const void* zero_page; // >= 64 zero bytes: LDS-DMA source for padding pixels
+    // SRC_STEM (bf16, gray): the 2->64 stem conv + BN + ReLU (unet.py:72) is evaluated inside the
+    // in-tile gather of the NEXT conv, so its 64-channel output never goes to HBM.
+    const float* f1;          // frame1 [B][1][H][W] fp32
+    const float* f2;          // frame2
+    const void* stem_w;       // [2 (hi, lo)][64 couts][32 k] bf16; k = dy*8 + dx*2 + frame, zero for dx = 3 or dy = 3
+    const float* stem_scale;  // [64]
+    const float* stem_shift;  // [64]
     unsigned long long* stamp;  // diagnostic builds (-DFIUNET_STAMP) only: 8 cycle sums per wave
     const float* head_w; // fused 1x1 head: [head_nc][64]
     const float* head_b; // [head_nc]
@@ -302,7 +310,12 @@ template <int BN, int TH, int TW, int MODE> struct ConvTile {
     static constexpr int SPARE_BYTES =
         (MODE == SRC_CONCAT_UP && LR_PIECES * 1024 > W_BYTES) ? LR_PIECES * 1024 - W_BYTES : 0;
     static constexpr int W_STRIDE = W_BYTES + SPARE_BYTES;  // slot 1 = slot 0 + W_STRIDE
-    static constexpr int LDS_BYTES = IN_BYTES + 2 * W_BYTES + SPARE_BYTES;
+    // SRC_STEM: raw fp32 patch of both frames, (TH+4) x (TW+4) pixels, after the ring
+    static constexpr int PATCH_W = TW + 4, PATCH_H = TH + 4;
+    static constexpr int PATCH_OFF = IN_BYTES + 2 * W_BYTES + SPARE_BYTES;
+    // two bf16 images (hi, lo) of [PATCH_H][PATCH_W][2 frames] + 64 B of zero pad each
+    static constexpr int PATCH_BYTES = MODE == SRC_STEM ? 2 * (PATCH_H * PATCH_W * 4 + 64) : 0;
+    static constexpr int LDS_BYTES = PATCH_OFF + ((PATCH_BYTES + 255) / 256) * 256;
     static_assert(LDS_BYTES <= 80 * 1024, "two workgroups must fit in the CU's 160 KiB of LDS");
 };
 
@@ -318,7 +331,9 @@ __global__ __launch_bounds__(256, 2) void conv3x3_mfma_kernel(const ConvArgs a)
     static_assert(TH == ROWS_W * WAVES_P, "wave tile must be 64 couts x 128 pixels");
     constexpr int HNC = EPI == EPI_HEAD ? 1 : (EPI == EPI_HEAD3 ? 3 : 0);  // fused-head classes
     static_assert(HNC == 0 || BN == 64, "fused head needs all 64 couts in one wave");
-    static_assert(MODE == SRC_DIRECT || MODE == SRC_CONCAT_UP, "pooling is fused into the producer");
+    static_assert(MODE == SRC_DIRECT || MODE == SRC_CONCAT_UP || MODE == SRC_STEM,
+                  "pooling is fused into the producer");
+    static_assert(MODE != SRC_STEM || (sizeof(T) == 2 && BN == 64), "fused stem: bf16, 64 couts");
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* const lds_in = smem;
@@ -485,8 +500,89 @@ __global__ __launch_bounds__(256, 2) void conv3x3_mfma_kernel(const ConvArgs a)
             *reinterpret_cast<uint4*>(lds_in + row * 64 + ((ch ^ swz(row)) << 4)) = v;
         }
     };
+    // ---- in-tile gather (c): SRC_STEM.  The plane's 32 channels of relu(bn(conv3x3(frames))) are
+    //      computed right here for the (TH+2)x(TW+2) window, from a raw fp32 patch of the two frames
+    //      staged once per tile.  bf16 MFMA with the operands split hi+lo (x = xh + xl, w = wh + wl;
+    //      xh*wh + xl*wh + xh*wl, fp32 accumulate) keeps ~2^-16 relative accuracy, far below the
+    //      bf16 rounding of the result.  k = tap*2 + frame (18 of 32 slots used).
+    constexpr int NIN = THP * (TW + 2);  // in-tile pixels
+    // patch image: bf16, [hi | lo][row][col][frame]; the 8 k-slots of lane group dy are then the 16
+    // contiguous bytes (4 columns x 2 frames) at (row + dy, col): k = dy*8 + dx*2 + frame, with zero
+    // weights for dx = 3 and dy = 3.
+    char* const patch = smem + Tile::PATCH_OFF;
+    constexpr int PW = Tile::PATCH_W, PH = Tile::PATCH_H;
+    constexpr int PATCH_HALF = Tile::PATCH_BYTES / 2;  // bytes of the hi (or lo) image incl. pad
+    auto stage_patch = [&]() __attribute__((always_inline)) {
+        if constexpr (MODE == SRC_STEM) {
+            unsigned short* const ph = reinterpret_cast<unsigned short*>(patch);
+            unsigned short* const pl = reinterpret_cast<unsigned short*>(patch + PATCH_HALF);
+            for (int i = tid; i < PATCH_HALF / 2; i += 256) {  // includes the zero pad at the end
+                const int f = i & 1, r = i >> 1;
+                const int py = r / PW, px = r - py * PW;
+                const int y = y0 - 2 + py, x = x0 - 2 + px;
+                const bool ok = (py < PH) & (y >= 0) & (y < aH) & (x >= 0) & (x < aW);
+                const float* src = f ? a.f2 : a.f1;
+                const float v = ok ? src[((size_t)b * aH + (ok ? y : 0)) * aW + (ok ? x : 0)] : 0.f;
+                const unsigned hi = pack_bf16x2(v, 0.f) & 0xffffu;
+                const unsigned lo = pack_bf16x2(v - __uint_as_float(hi << 16), 0.f) & 0xffffu;
+                ph[i] = (unsigned short)hi;
+                pl[i] = (unsigned short)lo;
+            }
+        }
+    };
+    auto gather_plane_stem = [&](int plane) __attribute__((always_inline)) {
+        if constexpr (MODE == SRC_STEM) {
+            // A operands (weights) of the plane's two 16-cout tiles, hi and lo parts
+            uint4 wh[2], wl[2];
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int row = (plane * 2 + h) * 16 + l15;
+                wh[h] = ldg16((const char*)a.stem_w + row * 64 + lc * 16);
+                wl[h] = ldg16((const char*)a.stem_w + 64 * 64 + row * 64 + lc * 16);
+            }
+            float4 ssc[2], ssh[2];
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                ssc[h] = *reinterpret_cast<const float4*>(a.stem_scale + (plane * 2 + h) * 16 + lc * 4);
+                ssh[h] = *reinterpret_cast<const float4*>(a.stem_shift + (plane * 2 + h) * 16 + lc * 4);
+            }
+            const int dy = min(lc, 2);  // lane group 3 multiplies zero weights: any finite data
+#pragma unroll 1
+            for (int q = wave; q * 16 < NIN; q += 4) {
+                const int i = min(q * 16 + l15, NIN - 1);
+                const int py = i / (TW + 2), px = i - py * (TW + 2);
+                const unsigned* const sh32 = reinterpret_cast<const unsigned*>(patch) + (py + dy) * PW + px;
+                const unsigned* const sl32 = reinterpret_cast<const unsigned*>(patch + PATCH_HALF) + (py + dy) * PW + px;
+                const uint4 bh = make_uint4(sh32[0], sh32[1], sh32[2], sh32[3]);
+                const uint4 bl = make_uint4(sl32[0], sl32[1], sl32[2], sl32[3]);
+                const int y = y0 - 1 + py, x = x0 - 1 + px;
+                const bool live = q * 16 + l15 < NIN;
+                const bool ok = live & (y >= 0) & (y < aH) & (x >= 0) & (x < aW);
+                const int row = py * TWP + px;
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    f32x4 s4 = f32x4{0.f, 0.f, 0.f, 0.f};
+                    mma_chunk<T>(s4, wl[h], bh);
+                    mma_chunk<T>(s4, wh[h], bl);
+                    mma_chunk<T>(s4, wh[h], bh);
+                    float o[4];
+                    o[0] = fmaxf(fmaf(s4[0], ssc[h].x, ssh[h].x), 0.f);
+                    o[1] = fmaxf(fmaf(s4[1], ssc[h].y, ssh[h].y), 0.f);
+                    o[2] = fmaxf(fmaf(s4[2], ssc[h].z, ssh[h].z), 0.f);
+                    o[3] = fmaxf(fmaf(s4[3], ssc[h].w, ssh[h].w), 0.f);
+                    // channels (h*16 + lc*4 .. +3) of the plane: chunk 2h + (lc>>1), 8-B half lc&1
+                    const int ch = 2 * h + (lc >> 1);
+                    const uint2 pk = ok ? make_uint2(pack_bf16x2(o[0], o[1]), pack_bf16x2(o[2], o[3]))
+                                        : make_uint2(0u, 0u);
+                    if (live)
+                        *reinterpret_cast<uint2*>(lds_in + row * 64 + ((ch ^ swz(row)) << 4) + (lc & 1) * 8) = pk;
+                }
+            }
+        }
+    };
     auto gather_plane = [&](int plane, int idle_slot) __attribute__((always_inline)) {
-        if (MODE == SRC_DIRECT || plane < p0) gather_plane_dma(plane);
+        if constexpr (MODE == SRC_STEM) gather_plane_stem(plane);
+        else if (MODE == SRC_DIRECT || plane < p0) gather_plane_dma(plane);
         else gather_plane_up(plane, idle_slot);
     };
 
@@ -502,6 +598,10 @@ __global__ __launch_bounds__(256, 2) void conv3x3_mfma_kernel(const ConvArgs a)
 #endif
     // W(0) goes to slot 0, so slot 1 (+ spare) is the idle staging area for plane 0
     issue_w(0);
+    if constexpr (MODE == SRC_STEM) {
+        stage_patch();
+        __syncthreads();
+    }
     gather_plane(0, 1);
     lds_dma_wait_all();
     __syncthreads();

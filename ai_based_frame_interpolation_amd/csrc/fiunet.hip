@@ -38,7 +38,7 @@ int fail(int code, const std::string& msg)
     } while (0)
 
 constexpr int NCONV = 18;
-constexpr size_t kStampWaves = 4 * 40000;  // diagnostic stamp records
+[[maybe_unused]] constexpr size_t kStampWaves = 4 * 40000;  // diagnostic stamp records
 // conv index = 2*block + {0,1}; blocks: inc, down1..4, up1..4 (state-dict order)
 const char* const kBlockPrefix[9] = {
     "unet.inc", "unet.down1.maxpool_conv.1", "unet.down2.maxpool_conv.1",
@@ -126,6 +126,7 @@ struct fiunet_ctx {
     float* head_w = nullptr;  // [cf][64]
     float* head_b = nullptr;  // [cf]
     void* zero_page = nullptr;  // 256 zero bytes (LDS-DMA source for conv padding)
+    void* stem_w_split = nullptr;  // gray stem weights as bf16 hi/lo pairs [2][64][32] (fused stem)
     unsigned long long* stamps = nullptr;  // per-wave cycle records (diagnostic -DFIUNET_STAMP builds)
     int stamp_layer = -1;
     std::vector<void*> owned;
@@ -217,6 +218,10 @@ template <typename T> int launch_conv(const ConvArgs& a, int mode, int epi, hipS
     if (mode == SRC_DIRECT && epi == EPI_HEAD) return launch_conv_shape<T, SRC_DIRECT, EPI_HEAD>(a, s);
     if (mode == SRC_DIRECT && epi == EPI_HEAD3) return launch_conv_shape<T, SRC_DIRECT, EPI_HEAD3>(a, s);
     if (mode == SRC_DIRECT && epi == EPI_POOL) return launch_conv_shape<T, SRC_DIRECT, EPI_POOL>(a, s);
+    if constexpr (sizeof(T) == 2) {
+        if (mode == SRC_STEM && epi == EPI_POOL && a.Cout == 64)  // 16x32 tiles only (LDS budget)
+            return launch_conv_cfg<T, 64, 16, 32, SRC_STEM, EPI_POOL>(a, s);
+    }
     return fail(FIUNET_ERR_INVALID_ARG, "unsupported gather/epilogue combination");
 }
 
@@ -243,8 +248,13 @@ int forward_impl(fiunet_ctx* ctx, const float* f1, const float* f2, float* out, 
         ctx->ev_used += NCONV + 1;
         HIP_TRY(hipEventRecord(ev[0], s));
     }
+    // bf16 gray network: the stem is evaluated inside conv 1's gather (SRC_STEM), unless the
+    // ablation path or the debug readback needs its output in HBM
+    const bool fuse_stem = bf16 && ctx->cf == 1 && !unfused && ctx->stem_w_split != nullptr &&
+                           padded_area(H, W, 16, 32) <= padded_area(H, W, 32, 16);
+    const bool run_stem = !fuse_stem || (ctx->flags & FIUNET_OPT_KEEP_ALL);
     // conv 0: fp32 stem (unet.py:72, first conv of inc)
-    {
+    if (run_stem) {
         const ConvWeights& cw = ctx->conv[0];
         const long long nruns = (long long)B * H * (((W + 15) / 16 + 7) / 8);  // 8-tile row runs
         dim3 grid((unsigned)std::min<long long>((nruns + 3) / 4, 256 * 64));
@@ -255,12 +265,14 @@ int forward_impl(fiunet_ctx* ctx, const float* f1, const float* f2, float* out, 
             hipLaunchKernelGGL((conv3x3_first_kernel<T, 3>), grid, dim3(256), 0, s, f1, f2,
                                (const float*)cw.w_f32, cw.scale, cw.shift, act(0), B, H, W);
         HIP_TRY(hipGetLastError());
-        if (ev) {
-            HIP_TRY(hipEventRecord(ev[1], s));
-            ctx->layer_name[0] = std::string("conv3x3_first_kernel<") + (bf16 ? "bf16" : "f32") + "," +
-                                 std::to_string(ctx->cf) + ">";
-            ctx->layer_flops[0] = 2.0 * B * H * W * 9.0 * cw.cin * cw.cout;
-        }
+    }
+    if (ev) {
+        const ConvWeights& cw = ctx->conv[0];
+        HIP_TRY(hipEventRecord(ev[1], s));
+        ctx->layer_name[0] = run_stem ? std::string("conv3x3_first_kernel<") + (bf16 ? "bf16" : "f32") +
+                                            "," + std::to_string(ctx->cf) + ">"
+                                      : std::string("(stem fused into next stage)");
+        ctx->layer_flops[0] = run_stem ? 2.0 * B * H * W * 9.0 * cw.cin * cw.cout : 0.0;
     }
     for (int i = 1; i < NCONV; ++i) {
         const ConvWeights& cw = ctx->conv[i];
@@ -301,6 +313,12 @@ int forward_impl(fiunet_ctx* ctx, const float* f1, const float* f2, float* out, 
             a.sx = 2 * a.lowW > 1 ? (float)(a.lowW - 1) / (float)(2 * a.lowW - 1) : 0.f;
         }
         if (a.C0 + a.C1 != cw.cin) return fail(FIUNET_ERR_INVALID_ARG, "internal: channel plan mismatch");
+        if (i == 1 && fuse_stem) {
+            mode = SRC_STEM;
+            a.f1 = f1; a.f2 = f2;
+            a.stem_w = ctx->stem_w_split;
+            a.stem_scale = ctx->conv[0].scale; a.stem_shift = ctx->conv[0].shift;
+        }
         if (unfused && mode == SRC_CONCAT_UP) {
             const size_t n = (size_t)B * a.H * a.W * ((a.C0 + a.C1) * sizeof(T) / 16);
             hipLaunchKernelGGL((upcat_kernel<T>), dim3(grid_for(n)), dim3(256), 0, s, a, scratch);
@@ -323,6 +341,8 @@ int forward_impl(fiunet_ctx* ctx, const float* f1, const float* f2, float* out, 
         if (rc != FIUNET_OK) return rc;
         if (ev) {
             ctx->layer_flops[i] = 2.0 * B * a.H * a.W * 9.0 * cw.cin * cw.cout;
+            if (i == 1 && fuse_stem && !run_stem)  // the fused stage also does the stem's FLOPs
+                ctx->layer_flops[i] += 2.0 * B * H * W * 9.0 * ctx->conv[0].cin * ctx->conv[0].cout;
             if (i < NCONV - 1 || !unfused) HIP_TRY(hipEventRecord(ev[i + 1], s));
         }
     }
@@ -437,6 +457,22 @@ int fiunet_load_weights(fiunet_ctx* ctx, int n, const char* const* names,
                     for (int t = 0; t < 9; ++t)
                         pk[((size_t)t * cin + ci) * 64 + co] = w[((size_t)co * cin + ci) * 9 + t];
             if ((rc = dev_upload(ctx, pk.data(), pk.size() * 4, &cw.w_f32))) return rc;
+            if (cin == 2) {  // fused-stem copy: w = hi + lo in bf16, [hi|lo][cout][k = dy*8 + dx*2 + frame]
+                std::vector<uint16_t> sp((size_t)2 * 64 * 32, 0);
+                for (int co = 0; co < 64; ++co)
+                    for (int k = 0; k < 24; ++k) {
+                        const int dy = k >> 3, dx = (k >> 1) & 3, f = k & 1;
+                        if (dx == 3) continue;
+                        const float v = w[((size_t)co * 2 + f) * 9 + dy * 3 + dx];
+                        const uint16_t hi = f32_to_bf16_rne(v);
+                        uint32_t hb = (uint32_t)hi << 16;
+                        float hf;
+                        std::memcpy(&hf, &hb, 4);
+                        sp[(size_t)co * 32 + k] = hi;
+                        sp[(size_t)64 * 32 + co * 32 + k] = f32_to_bf16_rne(v - hf);
+                    }
+                if ((rc = dev_upload(ctx, sp.data(), sp.size() * 2, &ctx->stem_w_split))) return rc;
+            }
             continue;
         }
         const size_t nel = (size_t)cout * cin * 9;

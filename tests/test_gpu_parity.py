@@ -106,9 +106,11 @@ def test_per_layer_golden_fixture_fp32(model, dev, golden_dir):
 
 
 def test_fused_equals_unfused_bitwise(model, dev):
-    """The fused pool / upsample+pad+concat gathers compute exactly what the standalone kernels
-    materialise, so all 18 stage outputs are bit-identical; only the 1x1 head differs (the
-    fused head reduces 64 channels in a different fp32 order and skips a bf16 rounding)."""
+    """The fused pool epilogue and the fused upsample+pad+concat gather compute exactly what the
+    standalone kernels materialise, so in fp32 all 18 stage outputs are bit-identical; only the
+    1x1 head differs (the fused head reduces 64 channels in a different fp32 order).  In bf16 the
+    fused path additionally evaluates the stem inside the next conv's gather with split-bf16 MFMA
+    (~2^-16 relative) instead of the exact-fp32 stem kernel, so stages agree to bf16 rounding."""
     f1, f2 = O.make_frames(21, 2, 50, 70)
     for prec in ("fp32", "bf16"):
         model.precision = prec
@@ -118,7 +120,11 @@ def test_fused_equals_unfused_bitwise(model, dev):
         acts_b, b = model.debug_activations(f1.to(dev), f2.to(dev))
         model.set_options()
         for k in acts_a:
-            assert torch.equal(acts_a[k], acts_b[k]), (prec, k)
+            if prec == "fp32":
+                assert torch.equal(acts_a[k], acts_b[k]), (prec, k)
+            else:
+                rel = (acts_a[k] - acts_b[k]).abs().max().item() / acts_b[k].abs().max().item()
+                assert rel <= 1e-2, (prec, k, rel)
         assert (a - b).abs().max().item() <= (1e-5 if prec == "fp32" else 2e-2)
 
 
