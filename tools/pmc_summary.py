@@ -11,6 +11,7 @@ import csv, glob, json, os, re, sys
 from collections import defaultdict
 
 src, out = sys.argv[1], sys.argv[2]
+NFW = int(sys.argv[3]) if len(sys.argv) > 3 else 4  # forwards in the profiled bench run
 
 def load(pass_name):
     files = glob.glob(os.path.join(src, pass_name, "*", "*_counter_collection.csv"))
@@ -25,10 +26,10 @@ def load(pass_name):
         d["lds"] = int(r["LDS_Block_Size"]); d["vgpr"] = int(r["VGPR_Count"])
         d["t"] = (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) * 1e-9
         d[r["Counter_Name"]] = d.get(r["Counter_Name"], 0.0) + float(r["Counter_Value"])
-    # the forward = stem + 17 convs; keep the LAST complete forward
+    # keep the LAST complete forward (bench ran NFW = warmup + steps forwards of identical launches)
     ids = sorted(k for k, v in disp.items() if "fiunet" in v["name"] and ("conv3x3" in v["name"]))
-    last = ids[-18:]
-    return [disp[i] for i in last]
+    per_fw = len(ids) // NFW
+    return [disp[i] for i in ids[-per_fw:]]
 
 def short(n):
     """same spelling as bench.py's roofline.kernel (fiunet_profile_read names)"""
@@ -41,7 +42,7 @@ def short(n):
 
 fetch, write, sq = load("fetch"), load("write"), load("sq")
 stages = []
-for i in range(18):
+for i in range(len(fetch)):
     f, w, s = fetch[i], write[i], sq[i]
     assert f["name"] == w["name"] == s["name"]
     rd = 2.0 * f["FETCH_SIZE"] * 1024.0
