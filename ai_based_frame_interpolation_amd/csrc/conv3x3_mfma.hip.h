@@ -452,6 +452,16 @@ __global__ __launch_bounds__(256, 2) void conv3x3_mfma_kernel(const ConvArgs a)
         }
     };
 
+#ifdef FIUNET_STAMP
+    unsigned long long st_sum[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long st_t0 = __builtin_amdgcn_s_memtime(), st_prev = st_t0;
+#define STAMP(slot) do { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); \
+                         st_sum[slot] += t_ - st_prev; st_prev = t_; } while (0)
+#define STAMP_UP(slot) STAMP(slot)
+#else
+#define STAMP(slot) do {} while (0)
+#define STAMP_UP(slot) do {} while (0)
+#endif
     // ---- in-tile gather (b): bilinearly upsampled planes.  The low-res source tile (<= LRH x LRW
     //      pixels of this plane) is DMA-ed into the idle weight slot + spare region, then every
     //      thread interpolates its chunks LDS -> LDS: one memory round trip per plane instead of
@@ -480,6 +490,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_mfma_kernel(const ConvArgs a)
         }
         lds_dma_wait_all();
         __syncthreads();
+        STAMP_UP(6);
         const char* const stg = lds_w + stg_off;
 #pragma unroll 2
         for (int i = tid; i < NCH; i += 256) {
@@ -499,7 +510,9 @@ __global__ __launch_bounds__(256, 2) void conv3x3_mfma_kernel(const ConvArgs a)
             const int row = py * TWP + px;
             *reinterpret_cast<uint4*>(lds_in + row * 64 + ((ch ^ swz(row)) << 4)) = v;
         }
+        STAMP_UP(7);
     };
+
     // ---- in-tile gather (c): SRC_STEM.  The plane's 32 channels of relu(bn(conv3x3(frames))) are
     //      computed right here for the (TH+2)x(TW+2) window, from a raw fp32 patch of the two frames
     //      staged once per tile.  bf16 MFMA with the operands split hi+lo (x = xh + xl, w = wh + wl;
@@ -516,17 +529,25 @@ __global__ __launch_bounds__(256, 2) void conv3x3_mfma_kernel(const ConvArgs a)
         if constexpr (MODE == SRC_STEM) {
             unsigned short* const ph = reinterpret_cast<unsigned short*>(patch);
             unsigned short* const pl = reinterpret_cast<unsigned short*>(patch + PATCH_HALF);
-            for (int i = tid; i < PATCH_HALF / 2; i += 256) {  // includes the zero pad at the end
+            constexpr int NE = PATCH_HALF / 2;        // elements incl. the zero pad at the end
+            constexpr int NB = (NE + 255) / 256;      // all loads are issued before the first use
+            float v[NB];
+#pragma unroll
+            for (int k = 0; k < NB; ++k) {
+                const int i = tid + k * 256;
                 const int f = i & 1, r = i >> 1;
                 const int py = r / PW, px = r - py * PW;
                 const int y = y0 - 2 + py, x = x0 - 2 + px;
-                const bool ok = (py < PH) & (y >= 0) & (y < aH) & (x >= 0) & (x < aW);
+                const bool ok = (i < NE) & (py < PH) & (y >= 0) & (y < aH) & (x >= 0) & (x < aW);
                 const float* src = f ? a.f2 : a.f1;
-                const float v = ok ? src[((size_t)b * aH + (ok ? y : 0)) * aW + (ok ? x : 0)] : 0.f;
-                const unsigned hi = pack_bf16x2(v, 0.f) & 0xffffu;
-                const unsigned lo = pack_bf16x2(v - __uint_as_float(hi << 16), 0.f) & 0xffffu;
-                ph[i] = (unsigned short)hi;
-                pl[i] = (unsigned short)lo;
+                v[k] = ok ? src[((size_t)b * aH + (ok ? y : 0)) * aW + (ok ? x : 0)] : 0.f;
+            }
+#pragma unroll
+            for (int k = 0; k < NB; ++k) {
+                const int i = tid + k * 256;
+                const unsigned hi = pack_bf16x2(v[k], 0.f) & 0xffffu;
+                const unsigned lo = pack_bf16x2(v[k] - __uint_as_float(hi << 16), 0.f) & 0xffffu;
+                if (i < NE) { ph[i] = (unsigned short)hi; pl[i] = (unsigned short)lo; }
             }
         }
     };
@@ -586,16 +607,9 @@ __global__ __launch_bounds__(256, 2) void conv3x3_mfma_kernel(const ConvArgs a)
         else gather_plane_up(plane, idle_slot);
     };
 
-#ifdef FIUNET_STAMP
-    // diagnostic build: where does a wave's time go?  [0] total [1] prologue [2] MFMA phases
-    // [3] end-of-step wait+barrier [4] plane-boundary gather [5] epilogue   (s_memtime ticks)
-    unsigned long long st_sum[6] = {0, 0, 0, 0, 0, 0};
-    unsigned long long st_t0 = __builtin_amdgcn_s_memtime(), st_prev = st_t0;
-#define STAMP(slot) do { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); \
-                         st_sum[slot] += t_ - st_prev; st_prev = t_; } while (0)
-#else
-#define STAMP(slot) do {} while (0)
-#endif
+    // diagnostic build (-DFIUNET_STAMP): where does a wave's time go?  [0] total [1] prologue
+    // [2] MFMA phases [3] end-of-step wait+barrier [4] plane-boundary gather (rest) [5] epilogue
+    // [6] upsample staging DMA + wait [7] upsample interpolation   (s_memtime ticks)
     // W(0) goes to slot 0, so slot 1 (+ spare) is the idle staging area for plane 0
     issue_w(0);
     if constexpr (MODE == SRC_STEM) {
@@ -789,6 +803,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_mfma_kernel(const ConvArgs a)
 #pragma unroll
         for (int k = 0; k < 6; ++k) rec[k] = st_sum[k];
         rec[6] = 1ull;
+        rec[7] = (st_sum[6] << 32) | (st_sum[7] & 0xffffffffull);
     }
 #endif
 }

@@ -174,12 +174,15 @@ int launch_conv_cfg(ConvArgs a, hipStream_t s)
     a.nct = a.Cout / BN;
     const long long nblk = (long long)a.B * a.tilesX * a.tilesY * a.nct;
     if (nblk <= 0 || nblk > 0x7fffffffLL) return fail(FIUNET_ERR_INVALID_ARG, "conv grid too large");
-    static bool lds_attr_set = false;  // > 64 KiB of dynamic LDS needs the opt-in attribute
-    if (!lds_attr_set) {
+    // > 64 KiB of dynamic LDS needs the opt-in attribute, once per kernel and device
+    static bool lds_attr_set[64] = {};
+    int dev = 0;
+    HIP_TRY(hipGetDevice(&dev));
+    if (dev >= 0 && dev < 64 && !lds_attr_set[dev]) {
         HIP_TRY(hipFuncSetAttribute(
             reinterpret_cast<const void*>(&conv3x3_mfma_kernel<T, BN, TH, TW, MODE, EPI>),
             hipFuncAttributeMaxDynamicSharedMemorySize, Tile::LDS_BYTES));
-        lds_attr_set = true;
+        lds_attr_set[dev] = true;
     }
     hipLaunchKernelGGL((conv3x3_mfma_kernel<T, BN, TH, TW, MODE, EPI>), dim3((unsigned)nblk),
                        dim3(256), Tile::LDS_BYTES, s, a);

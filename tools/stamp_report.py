@@ -26,4 +26,5 @@ for i in range(1, 18):
     L.fiunet_debug_stamps(m._ctx._h, buf)
     v = list(buf)
     nw = max(v[6], 1); tot = max(v[0], 1)
-    print(f"{i:5d} {nw:9d} {v[0] / nw:9.0f} " + " ".join(f"{100.0 * v[k] / tot:8.1f}%" for k in range(1, 6)))
+    print(f"{i:5d} {nw:9d} {v[0] / nw:9.0f} " + " ".join(f"{100.0 * v[k] / tot:8.1f}%" for k in range(1, 6))
+          + f"   up-dma {100.0 * (v[7] >> 32) / tot:5.1f}% up-lerp {100.0 * (v[7] & 0xffffffff) / tot:5.1f}%")
