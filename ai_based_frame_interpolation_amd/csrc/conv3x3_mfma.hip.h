@@ -1,25 +1,31 @@
 // conv3x3_mfma.hip.h -- fused 3x3 conv (pad 1, no bias) + per-channel scale/shift (eval BatchNorm)
-// + ReLU as an implicit GEMM on the CDNA4 matrix cores, NHWC, for gfx950 only.
+// + ReLU as an implicit GEMM on the CDNA4 matrix cores, for gfx950 only.
 //
 // Replaces the aten conv2d + batch_norm + relu triple behind DoubleConv
-// (/root/reference/model/unet.py:11-18) and, through the SRC_* gather modes, also the MaxPool2d
-// of Down (unet.py:28) and the Upsample + F.pad + torch.cat of Up (unet.py:46-54), which are
-// folded into the input-tile gather instead of being materialised in HBM.
+// (/root/reference/model/unet.py:11-18) and, fused around it, the other ops of the UNet forward:
+//   * MaxPool2d(2) of Down (unet.py:28)           -> EPI_POOL: the producer also writes the pooled copy
+//   * Upsample + F.pad + torch.cat of Up (:46-54) -> SRC_CONCAT_UP: interpolated inside the gather
+//   * OutConv 1x1 + bias (:60)                    -> EPI_HEAD / EPI_HEAD3: reduced in the epilogue
+//   * the 2->64 stem conv (:72), bf16 gray path   -> SRC_STEM: evaluated inside the gather
+// so none of the pooled-input re-reads, upsampled, concatenated, stem-output or last-activation
+// tensors is ever materialised in HBM.
 //
 // Mapping onto the hardware (one workgroup = 4 waves = 256 threads, 2 workgroups per CU):
 //   * GEMM view: D[cout][pixel] += W[cout][k] * X[k][pixel], k = (channel plane, ky, kx).
 //     MFMA A operand = weights (16 couts x 8k per lane-row), B operand = pixels.  With that
-//     orientation a lane of the 16x16 accumulator holds 4 consecutive couts of one pixel, so the
-//     NHWC epilogue stores 8 (bf16) / 16 (fp32) contiguous bytes per lane.
+//     orientation a lane of the 16x16 accumulator holds consecutive couts of one pixel, so the
+//     epilogue stores 16 contiguous bytes per lane into the blocked activation layout
+//     [B][C/PL][H][W][PL] (see blk_off below).
 //   * A "plane" is 64 bytes of channels per pixel (32 bf16 or 16 fp32).  The input tile
 //     (TH+2)x(TW+2) pixels of one plane is staged in LDS ONCE and reused by all 9 taps -- the
 //     shifted windows are just different LDS addresses (base + immediate offset).
 //   * Weights for (plane, ky, kx=0..2) are streamed per step: 3*BN rows of 64 B, by LDS-DMA
 //     (global_load_lds_dwordx4, 1 KiB per wave-instruction, no VGPRs) into a 2-deep ring, one
 //     step ahead of the MFMAs, so the L2 latency of the weight stream hides under the previous
-//     step's 96 MFMAs per wave.  The next plane's input tile is gathered (through registers:
-//     pool / bilinear transforms happen here) at the plane boundary behind one extra barrier;
-//     the co-resident second workgroup of the CU covers that gap.
+//     step's 96 MFMAs per wave.  The next plane's input tile is gathered at the plane boundary
+//     behind one extra barrier (LDS-DMA for stored planes; LDS-staged bilinear interpolation or
+//     the split-bf16 stem conv for computed ones); the co-resident second workgroup of the CU
+//     covers that gap.
 //   * Both LDS images are [row][64 B] with the 16-B chunk index XOR-ed by ((row>>2)&1)<<1, which
 //     makes every ds_read_b128 of 16 consecutive rows x 4 chunks conflict-free for any row
 //     alignment (the 16-lane groups of ds_read_b128 are listed in MI355X_MICROARCH.md, LDS).
@@ -31,10 +37,6 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
-
-#ifndef FIUNET_GB
-#define FIUNET_GB 2
-#endif
 
 namespace fiunet {
 
