@@ -1,0 +1,29 @@
+"""Stress: repeat forwards of several shapes, check bitwise determinism against the first result."""
+import os, sys, time, torch
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT)
+import ai_based_frame_interpolation_amd as P
+dev = torch.device("cuda:0")
+torch.manual_seed(0)
+m = P.FrameInterpolationUNet(bilinear=True, precision="bf16")
+with torch.no_grad():
+    for n, p in m.named_parameters():
+        if p.dim() == 4 and p.shape[-1] == 3: p.normal_(0, (2.0 / (p.shape[1] * 9)) ** 0.5)
+m = m.to(dev).eval()
+shapes = [(8, 1080, 1920), (1, 1080, 1920), (3, 270, 480), (2, 135, 241), (5, 64, 80), (1, 540, 960)]
+refs = {}
+t0 = time.time(); n = 0
+iters = int(sys.argv[1]) if len(sys.argv) > 1 else 40
+for it in range(iters):
+    for (b, h, w) in shapes:
+        g = torch.Generator(device=dev).manual_seed(b * 1000 + h)
+        f1 = torch.rand(b, 1, h, w, device=dev, generator=g) * 2 - 1
+        f2 = torch.rand(b, 1, h, w, device=dev, generator=g) * 2 - 1
+        out = m(f1, f2)
+        torch.cuda.synchronize()
+        key = (b, h, w)
+        if key not in refs: refs[key] = out.clone()
+        elif not torch.equal(out, refs[key]):
+            print("MISMATCH", key, it, (out - refs[key]).abs().max().item()); sys.exit(1)
+        n += 1
+    if it % 10 == 0: print(f"iter {it} ok, {n} forwards, {time.time() - t0:.1f} s", flush=True)
+print("STRESS OK", n, "forwards")
