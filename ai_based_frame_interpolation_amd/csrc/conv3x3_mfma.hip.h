@@ -80,6 +80,11 @@ struct ConvArgs {
     const void* stem_w;       // [2 (hi, lo)][64 couts][32 k] bf16; k = dy*8 + dx*2 + frame, zero for dx = 3 or dy = 3
     const float* stem_scale;  // [64]
     const float* stem_shift;  // [64]
+    // EPI_SPLITK: the K loop (planes) is cut into `ksplit` slices handled by different workgroups;
+    // slice s stores its raw fp32 partial sums to kslab[s][B*H*W][Cout]; splitk_finalize_kernel adds
+    // the slices in order (deterministic) and applies scale/shift/ReLU.
+    int ksplit;
+    float* kslab;
     unsigned long long* stamp;  // diagnostic builds (-DFIUNET_STAMP) only: 8 cycle sums per wave
     const float* head_w; // fused 1x1 head: [head_nc][64]
     const float* head_b; // [head_nc]
@@ -287,7 +292,8 @@ __device__ __forceinline__ void mma_chunk<float>(f32x4& acc, const uint4& wa, co
     acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(wa.w), __uint_as_float(xb.w), acc, 0, 0, 0);
 }
 
-enum Epilogue { EPI_PLAIN = 0, EPI_HEAD = 1 /* 1x1 head, 1 class */, EPI_POOL = 2, EPI_HEAD3 = 3 /* 3 classes */ };
+enum Epilogue { EPI_PLAIN = 0, EPI_HEAD = 1 /* 1x1 head, 1 class */, EPI_POOL = 2, EPI_HEAD3 = 3 /* 3 classes */,
+                EPI_SPLITK = 4 /* raw fp32 partial sums of a K slice -> slab (small problems) */ };
 
 // value of the neighbouring lane (lane ^ 1) through DPP quad_perm [1,0,3,2]: no LDS crossbar
 __device__ __forceinline__ unsigned dpp_swap_pairs(unsigned v)
@@ -351,6 +357,9 @@ __global__ __launch_bounds__(256, 2) void conv3x3_mfma_kernel(const ConvArgs a)
         const int q = nblk >> 3, r = nblk & 7, xcd = bid & 7;
         lid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
     }
+    const int ksplit = EPI == EPI_SPLITK ? a.ksplit : 1;
+    const int split = lid % ksplit;
+    lid /= ksplit;
     const int ct = lid % a.nct;
     int t = lid / a.nct;
     const int tx = t % a.tilesX; t /= a.tilesX;
@@ -376,9 +385,11 @@ __global__ __launch_bounds__(256, 2) void conv3x3_mfma_kernel(const ConvArgs a)
     for (int kx = 0; kx < 3; ++kx)
         b_off[kx] = (wp * ROWS_W * TWP + kx + l15) * 64 + ((lc ^ swz(kx + l15)) << 4);
 
-    const int nplanes = (a.C0 + a.C1) / PL;
+    const int nplanes_all = (a.C0 + a.C1) / PL;
     const int p0 = a.C0 / PL;
-    const int nsteps = nplanes * 3;
+    // this workgroup's K slice: planes [pbeg, pend)
+    const int pbeg = split * nplanes_all / ksplit, pend = (split + 1) * nplanes_all / ksplit;
+    const int nsteps = (pend - pbeg) * 3;
     const char* wbase = (const char*)a.wgt + (size_t)ct * BN * 64;
 
     // ---- weight stream: each wave moves NW 1-KiB pieces (16 LDS rows) per step by LDS-DMA.  The
@@ -391,8 +402,8 @@ __global__ __launch_bounds__(256, 2) void conv3x3_mfma_kernel(const ConvArgs a)
         const int kx = lrow / BN, row = lrow - kx * BN;
         w_src_off[j] = (kx * a.Cout + row) * 64 + (((lane & 3) ^ swz(lrow)) << 4);
     }
-    auto issue_w = [&](int step) __attribute__((always_inline)) {
-        const int pl = step / 3, ky = step - pl * 3;
+    auto issue_w = [&](int step) __attribute__((always_inline)) {  // step counts from this slice's start
+        const int lp = step / 3, ky = step - lp * 3, pl = pbeg + lp;
         const char* wsrc = wbase + ((size_t)(pl * 9 + ky * 3) * a.Cout) * 64;
         const unsigned dst = __builtin_amdgcn_readfirstlane(
             lds_w_addr + (unsigned)((step & 1) * Tile::W_STRIDE + wave * NW * 1024));
@@ -618,13 +629,13 @@ __global__ __launch_bounds__(256, 2) void conv3x3_mfma_kernel(const ConvArgs a)
         stage_patch();
         __syncthreads();
     }
-    gather_plane(0, 1);
+    gather_plane(pbeg, 1);
     lds_dma_wait_all();
     __syncthreads();
     STAMP(1);
 
     int step = 0;
-    for (int plane = 0; plane < nplanes; ++plane) {
+    for (int plane = pbeg; plane < pend; ++plane) {
 #pragma unroll
         for (int ky = 0; ky < 3; ++ky, ++step) {
             // W(step) and the in-tile of `plane` are resident.  Stream W(step+1) into the other
@@ -651,7 +662,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_mfma_kernel(const ConvArgs a)
             __builtin_amdgcn_sched_barrier(0);
 #endif
             STAMP(2);
-            if (ky == 2 && plane + 1 < nplanes) {
+            if (ky == 2 && plane + 1 < pend) {
                 __syncthreads();  // every wave is done with this plane's in-tile and with W(step)
                 gather_plane(plane + 1, step & 1);
                 lds_dma_wait_all();
@@ -677,6 +688,22 @@ __global__ __launch_bounds__(256, 2) void conv3x3_mfma_kernel(const ConvArgs a)
     auto cofs = [&](int m) __attribute__((always_inline)) {  // cout (within the wave) of register j=0
         return PERM ? (m >> 1) * 32 + lc * 8 + (m & 1) * 4 : m * 16 + lc * 4;
     };
+    if constexpr (EPI == EPI_SPLITK) {
+        float* const slab = a.kslab + (size_t)split * a.B * aH * aW * a.Cout;
+#pragma unroll
+        for (int n = 0; n < 8; ++n) {
+            const int y = y0 + wp * ROWS_W + n / FR;
+            const int x = x0 + (n % FR) * 16 + l15;
+            if (y < aH && x < aW) {
+                float* o = slab + (((size_t)b * aH + y) * aW + x) * a.Cout + wbase_c;
+#pragma unroll
+                for (int m = 0; m < 4; ++m)
+                    *reinterpret_cast<float4*>(o + cofs(m)) =
+                        make_float4(acc[m][n][0], acc[m][n][1], acc[m][n][2], acc[m][n][3]);
+            }
+        }
+        return;
+    }
     float4 sc[4], sh[4];
 #pragma unroll
     for (int m = 0; m < 4; ++m) {

@@ -38,6 +38,7 @@ int fail(int code, const std::string& msg)
     } while (0)
 
 constexpr int NCONV = 18;
+constexpr size_t kSlabBytes = 64u << 20;  // split-K slab: ksplit * B*H*W*Cout * 4 <= ~50 MB by construction
 [[maybe_unused]] constexpr size_t kStampWaves = 4 * 40000;  // diagnostic stamp records
 // conv index = 2*block + {0,1}; blocks: inc, down1..4, up1..4 (state-dict order)
 const char* const kBlockPrefix[9] = {
@@ -91,6 +92,7 @@ struct Plan {
     size_t act_off[NCONV];
     size_t pool_off[4];  // MaxPool2d(2) of x1..x4: kCout[2k+1] channels at level k+1
     size_t scratch_off;
+    size_t slab_off;   // split-K partial sums (small problems), kSlabBytes
     size_t total;
 };
 
@@ -111,6 +113,8 @@ bool make_plan(int B, int H, int W, int precision, Plan& p)
     }
     p.scratch_off = off;  // ablation path: concat tensor (<= 128 ch at level 0)
     off += align256((size_t)B * H * W * 128 * es);
+    p.slab_off = off;
+    off += kSlabBytes;
     p.total = off;
     return true;
 }
@@ -172,7 +176,7 @@ int launch_conv_cfg(ConvArgs a, hipStream_t s)
     a.tilesX = (a.W + TW - 1) / TW;
     a.tilesY = (a.H + TH - 1) / TH;
     a.nct = a.Cout / BN;
-    const long long nblk = (long long)a.B * a.tilesX * a.tilesY * a.nct;
+    const long long nblk = (long long)a.B * a.tilesX * a.tilesY * a.nct * (EPI == EPI_SPLITK ? a.ksplit : 1);
     if (nblk <= 0 || nblk > 0x7fffffffLL) return fail(FIUNET_ERR_INVALID_ARG, "conv grid too large");
     // > 64 KiB of dynamic LDS needs the opt-in attribute, once per kernel and device
     static bool lds_attr_set[64] = {};
@@ -190,6 +194,41 @@ int launch_conv_cfg(ConvArgs a, hipStream_t s)
     return FIUNET_OK;
 }
 
+inline unsigned grid_for(size_t n);
+
+// Small problems (fewer workgroups than half the CUs, e.g. the deep levels of a single 256x256 pair,
+// which is the only size the reference ever runs): cut the K loop over `ksplit` workgroups, then
+// reduce + scale/shift/ReLU (+ pool) in a finalize pass.  Deterministic (slices added in order).
+template <typename T, int BN, int TH, int TW, int MODE, int EPI>
+int launch_conv_maybe_split(ConvArgs a, hipStream_t s)
+{
+    if constexpr (MODE != SRC_STEM && (EPI == EPI_PLAIN || EPI == EPI_POOL)) {
+        const long long nblk = (long long)a.B * ((a.W + TW - 1) / TW) * ((a.H + TH - 1) / TH) * (a.Cout / BN);
+        const int nplanes = (a.C0 + a.C1) / Elem<T>::PL;
+        int ksplit = (int)std::min<long long>(std::min(nplanes / 2, 16), (256 + nblk - 1) / nblk);
+        while (ksplit > 1 && (size_t)ksplit * a.B * a.H * a.W * a.Cout * 4 > kSlabBytes) --ksplit;
+        if (nblk < 128 && ksplit > 1 && a.kslab && a.dst) {
+            ConvArgs k = a;
+            k.ksplit = ksplit;
+            int rc = launch_conv_cfg<T, BN, TH, TW, MODE, EPI_SPLITK>(k, s);
+            if (rc) return rc;
+            const size_t n = (size_t)a.B * a.H * a.W * (a.Cout / Elem<T>::NE);
+            hipLaunchKernelGGL((splitk_finalize_kernel<T>), dim3(grid_for(n)), dim3(256), 0, s, a.kslab,
+                               ksplit, a.scale, a.shift, (T*)a.dst, a.B, a.H, a.W, a.Cout, a.relu);
+            HIP_TRY(hipGetLastError());
+            if constexpr (EPI == EPI_POOL) {
+                const size_t np = (size_t)a.B * (a.H / 2) * (a.W / 2) * (a.Cout * sizeof(T) / 16);
+                hipLaunchKernelGGL((maxpool2_kernel<T>), dim3(grid_for(np)), dim3(256), 0, s,
+                                   (const T*)a.dst, (T*)a.pool_dst, a.B, a.H, a.W, a.Cout);
+                HIP_TRY(hipGetLastError());
+            }
+            if (g_name_out) *g_name_out += "+splitk" + std::to_string(ksplit);
+            return FIUNET_OK;
+        }
+    }
+    return launch_conv_cfg<T, BN, TH, TW, MODE, EPI>(a, s);
+}
+
 inline long long padded_area(int H, int W, int TH, int TW)
 {
     return (long long)((H + TH - 1) / TH) * TH * ((W + TW - 1) / TW) * TW;
@@ -199,14 +238,14 @@ template <typename T, int MODE, int EPI> int launch_conv_shape(const ConvArgs& a
 {
     if (a.Cout == 64) {
         const bool wide = padded_area(a.H, a.W, 16, 32) <= padded_area(a.H, a.W, 32, 16);
-        return wide ? launch_conv_cfg<T, 64, 16, 32, MODE, EPI>(a, s)
-                    : launch_conv_cfg<T, 64, 32, 16, MODE, EPI>(a, s);
+        return wide ? launch_conv_maybe_split<T, 64, 16, 32, MODE, EPI>(a, s)
+                    : launch_conv_maybe_split<T, 64, 32, 16, MODE, EPI>(a, s);
     }
     if constexpr (EPI != EPI_HEAD && EPI != EPI_HEAD3) {
         if (a.Cout % 128 != 0) return fail(FIUNET_ERR_INVALID_ARG, "Cout must be 64 or k*128");
         const bool wide = padded_area(a.H, a.W, 8, 32) <= padded_area(a.H, a.W, 16, 16);
-        return wide ? launch_conv_cfg<T, 128, 8, 32, MODE, EPI>(a, s)
-                    : launch_conv_cfg<T, 128, 16, 16, MODE, EPI>(a, s);
+        return wide ? launch_conv_maybe_split<T, 128, 8, 32, MODE, EPI>(a, s)
+                    : launch_conv_maybe_split<T, 128, 16, 16, MODE, EPI>(a, s);
     }
     return fail(FIUNET_ERR_INVALID_ARG, "fused head needs Cout == 64");
 }
@@ -288,6 +327,10 @@ int forward_impl(fiunet_ctx* ctx, const float* f1, const float* f2, float* out, 
         a.scale = cw.scale; a.shift = cw.shift;
         a.relu = 1;
         a.zero_page = ctx->zero_page;
+        a.ksplit = 1;
+        // the last conv is never K-split: its fused-head form cannot be, and the ablation path must
+        // accumulate in the same order to stay bit-identical with it
+        a.kslab = i == NCONV - 1 ? nullptr : (float*)(ws + p.slab_off);
         a.stamp = (ctx->stamps && i == ctx->stamp_layer) ? ctx->stamps : nullptr;
         a.dst = act(i);
         int mode = kMode[i];

@@ -186,6 +186,46 @@ __global__ __launch_bounds__(256) void head1x1_kernel(const T* __restrict__ src,
     for (int k = 0; k < nc; ++k) out[(b * nc + k) * HW + p] = acc[k] + bias[k];
 }
 
+// Split-K finalize (small problems): out = relu(scale * sum_s slab[s] + shift), slices added in
+// index order (deterministic); slab is [ksplit][B*H*W][C] fp32, out is the blocked layout.
+// thread = (pixel, 16-byte output chunk)
+template <typename T>
+__global__ __launch_bounds__(256) void splitk_finalize_kernel(const float* __restrict__ slab, int ksplit,
+                                                              const float* __restrict__ scale,
+                                                              const float* __restrict__ shift,
+                                                              T* __restrict__ dst, int B, int H, int W,
+                                                              int C, int relu)
+{
+    constexpr int NE = Elem<T>::NE, PL = Elem<T>::PL;
+    const int cpp = C / NE;  // chunks per pixel
+    const size_t npix = (size_t)B * H * W, total = npix * cpp;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        const int cc = (int)(i % cpp);
+        const size_t pix = i / cpp;
+        const int c0 = cc * NE;
+        float v[NE];
+#pragma unroll
+        for (int e = 0; e < NE; ++e) v[e] = 0.f;
+        for (int s = 0; s < ksplit; ++s) {
+            const float* p = slab + ((size_t)s * npix + pix) * C + c0;
+#pragma unroll
+            for (int e = 0; e < NE; e += 4) {
+                const float4 q = *reinterpret_cast<const float4*>(p + e);
+                v[e] += q.x; v[e + 1] += q.y; v[e + 2] += q.z; v[e + 3] += q.w;
+            }
+        }
+#pragma unroll
+        for (int e = 0; e < NE; ++e) {
+            v[e] = fmaf(v[e], scale[c0 + e], shift[c0 + e]);
+            if (relu) v[e] = fmaxf(v[e], 0.f);
+        }
+        const size_t b = pix / ((size_t)H * W), r = pix - b * (size_t)H * W;
+        char* o = (char*)dst + b * (size_t)H * W * C * sizeof(T) + ((size_t)(c0 / PL) * H * W + r) * 64 +
+                  (size_t)(c0 % PL) * sizeof(T);
+        *reinterpret_cast<uint4*>(o) = chunk_pack<T>(v);
+    }
+}
+
 template <typename T>
 __global__ __launch_bounds__(256) void nhwc_to_nchw_f32_kernel(const T* __restrict__ src,
                                                                float* __restrict__ dst, int B,
