@@ -1,0 +1,86 @@
+/* Plain-C consumer of the C ABI (include/fiunet.h): no Python, no torch, only the HIP runtime for
+ * device memory.  Loads a weight blob + two frames from files, runs fiunet_forward in both
+ * precisions and writes the outputs.  tests/test_gpu_cabi.py builds and runs it, then compares the
+ * outputs with the oracle.
+ *
+ * blob format (little endian): int32 n_tensors; per tensor: int32 name_len, name bytes, int64 numel,
+ * float32 data[numel].  frames file: int32 B, H, W; float32 f1[B*H*W], f2[B*H*W].
+ */
+#include <hip/hip_runtime_api.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "../../include/fiunet.h"
+
+#define CK(x) do { int rc_ = (x); if (rc_) { fprintf(stderr, "%s failed: %d (%s)\n", #x, rc_, fiunet_last_error_string()); return 2; } } while (0)
+#define HK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "%s: %s\n", #x, hipGetErrorString(e_)); return 3; } } while (0)
+
+int main(int argc, char** argv)
+{
+    if (argc < 4) { fprintf(stderr, "usage: %s weights.bin frames.bin out_prefix\n", argv[0]); return 1; }
+    FILE* f = fopen(argv[1], "rb");
+    if (!f) return 1;
+    int32_t n = 0;
+    if (fread(&n, 4, 1, f) != 1) return 1;
+    char** names = (char**)calloc(n, sizeof(char*));
+    float** data = (float**)calloc(n, sizeof(float*));
+    int64_t* numel = (int64_t*)calloc(n, sizeof(int64_t));
+    for (int i = 0; i < n; ++i) {
+        int32_t len = 0;
+        if (fread(&len, 4, 1, f) != 1) return 1;
+        names[i] = (char*)calloc(len + 1, 1);
+        if (fread(names[i], 1, len, f) != (size_t)len) return 1;
+        if (fread(&numel[i], 8, 1, f) != 1) return 1;
+        data[i] = (float*)malloc(sizeof(float) * numel[i]);
+        if (fread(data[i], 4, numel[i], f) != (size_t)numel[i]) return 1;
+    }
+    fclose(f);
+    f = fopen(argv[2], "rb");
+    if (!f) return 1;
+    int32_t dims[3];
+    if (fread(dims, 4, 3, f) != 3) return 1;
+    const int B = dims[0], H = dims[1], W = dims[2];
+    const size_t npx = (size_t)B * H * W;
+    float* h1 = (float*)malloc(4 * npx);
+    float* h2 = (float*)malloc(4 * npx);
+    float* ho = (float*)malloc(4 * npx);
+    if (fread(h1, 4, npx, f) != npx || fread(h2, 4, npx, f) != npx) return 1;
+    fclose(f);
+
+    fiunet_ctx* ctx = NULL;
+    if (fiunet_abi_version() != FIUNET_ABI_VERSION) return 4;
+    CK(fiunet_create(&ctx, 0, 1, 1));
+    CK(fiunet_load_weights(ctx, n, (const char* const*)names, (const float* const*)data, numel));
+    /* error paths of the ABI */
+    if (fiunet_workspace_bytes(ctx, 1, 8, 8, FIUNET_FP32) != 0) return 5;   /* too small: 0 */
+    float *d1, *d2, *dout;
+    HK(hipMalloc((void**)&d1, 4 * npx));
+    HK(hipMalloc((void**)&d2, 4 * npx));
+    HK(hipMalloc((void**)&dout, 4 * npx));
+    HK(hipMemcpy(d1, h1, 4 * npx, hipMemcpyHostToDevice));
+    HK(hipMemcpy(d2, h2, 4 * npx, hipMemcpyHostToDevice));
+    if (fiunet_forward(ctx, d1, d2, dout, B, H, W, FIUNET_FP32, d1, 16, NULL) != FIUNET_ERR_WORKSPACE) return 6;
+    hipStream_t stream;
+    HK(hipStreamCreate(&stream));
+    for (int prec = 0; prec < 2; ++prec) {
+        const size_t wsb = fiunet_workspace_bytes(ctx, B, H, W, prec);
+        if (!wsb) return 7;
+        void* ws = NULL;
+        HK(hipMalloc(&ws, wsb));
+        CK(fiunet_forward(ctx, d1, d2, dout, B, H, W, prec, ws, wsb, (void*)stream));
+        HK(hipStreamSynchronize(stream));
+        HK(hipMemcpy(ho, dout, 4 * npx, hipMemcpyDeviceToHost));
+        char path[512];
+        snprintf(path, sizeof path, "%s_%s.bin", argv[3], prec ? "bf16" : "fp32");
+        FILE* o = fopen(path, "wb");
+        if (!o) return 1;
+        fwrite(ho, 4, npx, o);
+        fclose(o);
+        HK(hipFree(ws));
+    }
+    CK(fiunet_destroy(ctx));
+    printf("abi_smoke ok B=%d H=%d W=%d\n", B, H, W);
+    return 0;
+}

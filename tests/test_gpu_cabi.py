@@ -1,0 +1,47 @@
+"""GPU: the C ABI is usable from plain C (no Python/torch in the consumer): build tests/c_abi/abi_smoke.c
+against include/fiunet.h + libfiunet_hip.so, run it, compare its outputs with the oracle."""
+import os
+import struct
+import subprocess
+
+import numpy as np
+import pytest
+import torch
+
+from ai_based_frame_interpolation_amd import _native
+from oracle import unet_oracle as O
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_plain_c_consumer(tmp_path, seeded_sd, hip_lib_built):
+    exe = tmp_path / "abi_smoke"
+    libdir = os.path.dirname(hip_lib_built)
+    cmd = ["gcc", "-O1", "-D__HIP_PLATFORM_AMD__", "-I/opt/rocm/include",
+           os.path.join(ROOT, "tests", "c_abi", "abi_smoke.c"), "-o", str(exe),
+           "-L" + libdir, "-lfiunet_hip", "-L/opt/rocm/lib", "-lamdhip64",
+           "-Wl,-rpath," + libdir, "-Wl,-rpath,/opt/rocm/lib"]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    wpath, fpath = tmp_path / "w.bin", tmp_path / "f.bin"
+    with open(wpath, "wb") as f:
+        items = [(k, v) for k, v in seeded_sd.items() if not k.endswith("num_batches_tracked")]
+        f.write(struct.pack("<i", len(items)))
+        for k, v in items:
+            kb = k.encode()
+            f.write(struct.pack("<i", len(kb))); f.write(kb)
+            f.write(struct.pack("<q", v.numel()))
+            f.write(v.detach().float().contiguous().numpy().tobytes())
+    b, h, w = 2, 40, 56
+    f1, f2 = O.make_frames(77, b, h, w)
+    with open(fpath, "wb") as f:
+        f.write(struct.pack("<iii", b, h, w))
+        f.write(f1.numpy().tobytes()); f.write(f2.numpy().tobytes())
+    r = subprocess.run([str(exe), str(wpath), str(fpath), str(tmp_path / "out")], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout + r.stderr
+    ref = O.unet_forward(seeded_sd, f1, f2).numpy()
+    o32 = np.fromfile(tmp_path / "out_fp32.bin", dtype=np.float32).reshape(ref.shape)
+    o16 = np.fromfile(tmp_path / "out_bf16.bin", dtype=np.float32).reshape(ref.shape)
+    assert np.abs(o32 - ref).max() <= 1e-3
+    assert np.linalg.norm(o16 - ref) / np.linalg.norm(ref) <= 2e-2
