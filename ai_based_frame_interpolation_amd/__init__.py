@@ -1,7 +1,7 @@
 """MI355X-native UNet frame-interpolation forward (drop-in for the reference's model/unet.py
 hot path).  See DESIGN.md / INTEGRATION.md.  The HIP extension (libfiunet_hip.so) is loaded
 lazily on the first forward; nothing here falls back to CPU."""
-from .unet import FrameInterpolationUNet, UNet, count_parameters  # noqa: F401
+from .unet import FrameInterpolationUNet, GraphedForward, UNet, count_parameters  # noqa: F401
 from .inference import (  # noqa: F401
     FrameInterpolator, generate_multiple_intermediate_frames, interpolate_frames,
     interpolate_sequence, load_model, postprocess_image, preprocess_image,
@@ -9,7 +9,7 @@ from .inference import (  # noqa: F401
 from . import video  # noqa: F401
 
 __all__ = [
-    "FrameInterpolationUNet", "UNet", "count_parameters", "FrameInterpolator",
+    "FrameInterpolationUNet", "GraphedForward", "UNet", "count_parameters", "FrameInterpolator",
     "generate_multiple_intermediate_frames", "interpolate_frames", "interpolate_sequence",
     "load_model", "postprocess_image", "preprocess_image", "video",
 ]

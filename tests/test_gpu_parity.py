@@ -261,3 +261,17 @@ def test_reference_inference_helpers_on_gpu(model, dev, tmp_path, seeded_sd):
     assert d.max() <= 1 and (d != 0).mean() <= 1e-3
     frames = P.generate_multiple_intermediate_frames(m, t1, t2, 3, dev)
     assert len(frames) == 3 and all(torch.equal(f, frames[0]) for f in frames)
+
+
+def test_hip_graph_replay_is_bit_identical(model, dev):
+    """fiunet_forward neither allocates nor synchronises, so a forward captures into a HIP graph."""
+    model.precision = "bf16"
+    model.set_options()
+    f1, f2 = O.make_frames(41, 1, 64, 96)
+    f1, f2 = f1.to(dev), f2.to(dev)
+    ref = model(f1, f2).clone()
+    g = P.GraphedForward(model, 1, 64, 96)
+    for _ in range(3):
+        assert torch.equal(g(f1, f2), ref)
+    g1, g2 = O.make_frames(42, 1, 64, 96)
+    assert torch.equal(g(g1.to(dev), g2.to(dev)), model(g1.to(dev), g2.to(dev)))
