@@ -275,3 +275,33 @@ def test_hip_graph_replay_is_bit_identical(model, dev):
         assert torch.equal(g(f1, f2), ref)
     g1, g2 = O.make_frames(42, 1, 64, 96)
     assert torch.equal(g(g1.to(dev), g2.to(dev)), model(g1.to(dev), g2.to(dev)))
+
+
+def test_module_state_stays_in_sync_with_device_weights(dev, seeded_sd):
+    """load_state_dict / in-place edits + refresh_weights() after a forward re-upload the weights;
+    non-contiguous and half-precision inputs behave like the reference's nn.Module would."""
+    m = P.FrameInterpolationUNet(bilinear=True)
+    m.load_state_dict(seeded_sd)
+    m = m.to(dev).eval()
+    f1, f2 = O.make_frames(51, 2, 40, 48)
+    a = m(f1.to(dev), f2.to(dev)).cpu()
+    sd2 = O.make_seeded_state_dict(999)
+    m.load_state_dict(sd2)
+    b = m(f1.to(dev), f2.to(dev)).cpu()
+    assert (b - O.unet_forward(sd2, f1, f2)).abs().max().item() <= FP32_TOL
+    assert (a - b).abs().max().item() > 1e-2
+    with torch.no_grad():
+        m.unet.outc.conv.bias.add_(1.0)
+    m.refresh_weights()
+    c = m(f1.to(dev), f2.to(dev)).cpu()
+    assert (c - (b + 1.0)).abs().max().item() <= 1e-5
+    # non-contiguous views and fp16 inputs
+    big1 = torch.zeros(2, 1, 40, 96, device=dev); big2 = torch.zeros(2, 1, 40, 96, device=dev)
+    big1[..., ::2] = f1.to(dev); big2[..., ::2] = f2.to(dev)
+    d = m(big1[..., ::2], big2[..., ::2]).cpu()
+    assert torch.equal(d, c)
+    e = m(f1.to(dev).half(), f2.to(dev).half())
+    assert e.dtype == torch.float16 and e.shape == (2, 1, 40, 48)
+    ref_h = O.unet_forward({k: (v + 1.0 if k == "unet.outc.conv.bias" else v) for k, v in sd2.items()},
+                           f1.half().float(), f2.half().float())
+    assert (e.float().cpu() - ref_h).abs().max().item() <= 5e-3
