@@ -4,12 +4,13 @@ lazily on the first forward; nothing here falls back to CPU."""
 from .unet import FrameInterpolationUNet, GraphedForward, UNet, count_parameters  # noqa: F401
 from .inference import (  # noqa: F401
     FrameInterpolator, generate_multiple_intermediate_frames, interpolate_frames,
-    interpolate_sequence, load_model, postprocess_image, preprocess_image,
+    interpolate_sequence, interpolate_sequence_host, load_model, postprocess_image, preprocess_image,
 )
 from . import video  # noqa: F401
 
 __all__ = [
     "FrameInterpolationUNet", "GraphedForward", "UNet", "count_parameters", "FrameInterpolator",
     "generate_multiple_intermediate_frames", "interpolate_frames", "interpolate_sequence",
+    "interpolate_sequence_host",
     "load_model", "postprocess_image", "preprocess_image", "video",
 ]

@@ -305,3 +305,12 @@ def test_module_state_stays_in_sync_with_device_weights(dev, seeded_sd):
     ref_h = O.unet_forward({k: (v + 1.0 if k == "unet.outc.conv.bias" else v) for k, v in sd2.items()},
                            f1.half().float(), f2.half().float())
     assert (e.float().cpu() - ref_h).abs().max().item() <= 5e-3
+
+
+def test_host_resident_video_loop_matches_device_loop(model, dev):
+    gen = torch.Generator().manual_seed(8)
+    fr = torch.randint(0, 256, (11, 40, 64), dtype=torch.uint8, generator=gen)
+    model.precision = "bf16"
+    a = P.interpolate_sequence_host(model, fr, batch=4)
+    b = P.interpolate_sequence(model, fr.to(dev), batch=4).cpu()
+    assert a.shape == (21, 40, 64) and torch.equal(a, b)
