@@ -67,6 +67,21 @@ def moving_pattern(t, h, w, device):
     return img.clamp(0, 255).to(torch.uint8)
 
 
+class _quiet_native_stdout:
+    """RCCL prints a version banner on fd 1 when its communicator is created; bench.py must print
+    exactly one JSON line, so native stdout is parked on stderr around that point."""
+
+    def __enter__(self):
+        sys.stdout.flush()
+        self._saved = os.dup(1)
+        os.dup2(2, 1)
+
+    def __exit__(self, *exc):
+        sys.stdout.flush()
+        os.dup2(self._saved, 1)
+        os.close(self._saved)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -90,7 +105,11 @@ def main():
     if world > 1 or "RANK" in os.environ:  # under torch.distributed.run (also with one rank)
         import torch.distributed as dist
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local_rank}"))
+        with _quiet_native_stdout():
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local_rank}"))
+            dist.barrier()  # creates the RCCL communicator (and prints its banner) here, not later
+            torch.cuda.synchronize()
     torch.cuda.set_device(local_rank)
     dev = torch.device(f"cuda:{local_rank}")
 
