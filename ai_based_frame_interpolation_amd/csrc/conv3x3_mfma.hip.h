@@ -191,10 +191,52 @@ __device__ __forceinline__ uint4 chunk_bilerp(const uint4& a, const uint4& b, co
     return chunk_pack<T>(r);
 }
 
+// The two halves of chunk_bilerp, for callers that walk down a column and reuse the horizontal
+// result of a low-res row for every output row that touches it.  Same operations on the same
+// operands in the same order as chunk_bilerp, hence the same bits.
+template <typename T>
+__device__ __forceinline__ void chunk_hlerp(const uint4& a, const uint4& b, float hx, float lx, float* h)
+{
+    constexpr int NE = Elem<T>::NE;
+    float fa[NE], fb[NE];
+    chunk_unpack<T>(a, fa); chunk_unpack<T>(b, fb);
+#pragma unroll
+    for (int i = 0; i < NE; ++i) h[i] = fmaf(lx, fb[i], __fmul_rn(hx, fa[i]));
+}
+template <typename T>
+__device__ __forceinline__ uint4 chunk_vlerp(const float* top, const float* bot, float hy, float ly)
+{
+    constexpr int NE = Elem<T>::NE;
+    float r[NE];
+#pragma unroll
+    for (int i = 0; i < NE; ++i) r[i] = fmaf(ly, bot[i], __fmul_rn(hy, top[i]));
+    return chunk_pack<T>(r);
+}
+
 __device__ __forceinline__ uint4 ldg16(const char* p) { return *reinterpret_cast<const uint4*>(p); }
 
 // Bilinear x2 (align_corners=True) source coordinates and weights of one upsampled+padded pixel
 // (unet.py:40,49-53), shared by every kernel that upsamples so they agree bit for bit.
+struct UpAxis {
+    int i0, i1;   // low-res source indices
+    float h, l;   // weights of i0, i1
+    bool ok;      // inside the upsampled extent (false: F.pad zero)
+};
+// one axis of the mapping: c = conv-input coordinate (already clamped to the image)
+__device__ __forceinline__ UpAxis up_axis(int c, int pad, int lowN, float scale)
+{
+    UpAxis u;
+    int cu = c - pad;
+    u.ok = (cu >= 0) & (cu < 2 * lowN);
+    cu = min(max(cu, 0), 2 * lowN - 1);
+    // f is the ROUNDED product, as in aten (the library is built with -ffp-contract=off)
+    const float f = scale * (float)cu;
+    u.i0 = (int)f;
+    u.i1 = u.i0 < lowN - 1 ? u.i0 + 1 : u.i0;
+    u.l = f - (float)u.i0;
+    u.h = 1.0f - u.l;
+    return u;
+}
 struct UpCoord {
     int y0, y1, x0, x1;
     float hy, ly, hx, lx;
@@ -202,18 +244,11 @@ struct UpCoord {
 };
 __device__ __forceinline__ UpCoord up_coord(const ConvArgs& a, int y, int x)
 {
+    const UpAxis v = up_axis(y, a.padT, a.lowH, a.sy), h = up_axis(x, a.padL, a.lowW, a.sx);
     UpCoord u;
-    int yu = y - a.padT, xu = x - a.padL;
-    u.ok = (yu >= 0) & (yu < 2 * a.lowH) & (xu >= 0) & (xu < 2 * a.lowW);
-    yu = min(max(yu, 0), 2 * a.lowH - 1);
-    xu = min(max(xu, 0), 2 * a.lowW - 1);
-    // fy is the ROUNDED product, as in aten (the library is built with -ffp-contract=off)
-    const float fy = a.sy * (float)yu, fx = a.sx * (float)xu;
-    u.y0 = (int)fy; u.x0 = (int)fx;
-    u.y1 = u.y0 < a.lowH - 1 ? u.y0 + 1 : u.y0;
-    u.x1 = u.x0 < a.lowW - 1 ? u.x0 + 1 : u.x0;
-    u.ly = fy - (float)u.y0; u.lx = fx - (float)u.x0;
-    u.hy = 1.0f - u.ly; u.hx = 1.0f - u.lx;
+    u.y0 = v.i0; u.y1 = v.i1; u.hy = v.h; u.ly = v.l;
+    u.x0 = h.i0; u.x1 = h.i1; u.hx = h.h; u.lx = h.l;
+    u.ok = v.ok & h.ok;
     return u;
 }
 
@@ -301,6 +336,19 @@ __device__ __forceinline__ unsigned dpp_swap_pairs(unsigned v)
     return (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xF, 0xF, true);
 }
 
+// number of row segments for the column-walk upsample (see gather_plane_up): minimise
+// passes over the 256 threads x (rows per segment + ~1 row of segment start-up)
+constexpr int up_segments(int rows, int ncol)
+{
+    int best = 1, best_cost = 1 << 30;
+    for (int n = 1; n <= 6; ++n) {
+        const int passes = (n * ncol + 255) / 256, segr = (rows + n - 1) / n;
+        const int cost = passes * (segr * 4 + 3);
+        if (cost < best_cost) { best_cost = cost; best = n; }
+    }
+    return best;
+}
+
 // LDS map of one workgroup (<= 80 KiB so that two fit on a CU):
 //   [ in-tile | W slot 0 | spare | W slot 1 ]
 // The spare region sits between the two ring slots so that, whichever slot is idle at a plane
@@ -327,16 +375,27 @@ template <int BN, int TH, int TW, int MODE> struct ConvTile {
     static_assert(LDS_BYTES <= 80 * 1024, "two workgroups must fit in the CU's 160 KiB of LDS");
 };
 
+// 16-pixel fragments per wave: 8 (wave tile 64 couts x 128 pixels, 128 accumulator registers, two
+// workgroups per CU) or 4 (64 x 64, 64 accumulator registers, three workgroups per CU: for the
+// short-K full-resolution layers, whose prologue/epilogue share is large, a third resident wave per
+// SIMD keeps the MFMA pipe fed while the other two gather or store).
+constexpr int conv_wave_frags(int BN, int TH, int TW) { return TH * TW / 16 / (4 / (BN / 64)); }
+constexpr int conv_occupancy(int BN, int TH, int TW) { return conv_wave_frags(BN, TH, TW) == 4 ? 3 : 2; }
+
 template <typename T, int BN, int TH, int TW, int MODE, int EPI>
-__global__ __launch_bounds__(256, 2) void conv3x3_mfma_kernel(const ConvArgs a)
+__global__ __launch_bounds__(256, conv_occupancy(BN, TH, TW)) void conv3x3_mfma_kernel(const ConvArgs a)
 {
     using Tile = ConvTile<BN, TH, TW, MODE>;
     constexpr int PL = Elem<T>::PL;
     constexpr int TWP = Tile::TWP, THP = Tile::THP;
     constexpr int WAVES_C = BN / 64, WAVES_P = 4 / WAVES_C;
     constexpr int FR = TW / 16;       // 16-pixel fragments per tile row
-    constexpr int ROWS_W = 8 / FR;    // tile rows per wave
-    static_assert(TH == ROWS_W * WAVES_P, "wave tile must be 64 couts x 128 pixels");
+    constexpr int NF = conv_wave_frags(BN, TH, TW);  // fragments per wave
+    constexpr int ROWS_W = NF / FR;   // tile rows per wave
+    static_assert(NF == 8 || NF == 4, "wave tile must be 64 couts x 128 or 64 pixels");
+    static_assert(TH == ROWS_W * WAVES_P && ROWS_W * FR == NF, "tile does not split over the waves");
+    static_assert(EPI != EPI_POOL || ROWS_W % 2 == 0, "pooled epilogue: a wave owns whole row pairs");
+    static_assert(Tile::LDS_BYTES * conv_occupancy(BN, TH, TW) <= 160 * 1024, "LDS per CU");
     constexpr int HNC = EPI == EPI_HEAD ? 1 : (EPI == EPI_HEAD3 ? 3 : 0);  // fused-head classes
     static_assert(HNC == 0 || BN == 64, "fused head needs all 64 couts in one wave");
     static_assert(MODE == SRC_DIRECT || MODE == SRC_CONCAT_UP || MODE == SRC_STEM,
@@ -372,11 +431,11 @@ __global__ __launch_bounds__(256, 2) void conv3x3_mfma_kernel(const ConvArgs a)
     const int l15 = lane & 15, lc = lane >> 4;
     const int wc = wave % WAVES_C, wp = wave / WAVES_C;
 
-    f32x4 acc[4][8];
+    f32x4 acc[4][NF];
 #pragma unroll
     for (int m = 0; m < 4; ++m)
 #pragma unroll
-        for (int n = 0; n < 8; ++n) acc[m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int n = 0; n < NF; ++n) acc[m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     // per-lane LDS read offsets (everything else is an immediate)
     const int a_off = (wc * 64 + l15) * 64 + ((lc ^ swz(l15)) << 4);  // within a weight ring slot
@@ -479,7 +538,11 @@ __global__ __launch_bounds__(256, 2) void conv3x3_mfma_kernel(const ConvArgs a)
     //      pixels of this plane) is DMA-ed into the idle weight slot + spare region, then every
     //      thread interpolates its chunks LDS -> LDS: one memory round trip per plane instead of
     //      one per batch of register loads, and no VGPRs held across it. ---------------------------
-    constexpr int NCH = THP * (TW + 2) * 4;
+    // (pixel column, chunk) pairs of one in-tile row, and the number of row segments a column is
+    // cut into so that the tasks fill the 256 threads: cost ~ passes * (rows per segment + 1)
+    constexpr int UP_NCOL = (TW + 2) * 4;
+    constexpr int UP_NSEG = up_segments(THP, UP_NCOL);
+    constexpr int UP_SEGR = (THP + UP_NSEG - 1) / UP_NSEG;
     int lr_y = 0, lr_x = 0;  // low-res origin of this tile's staging window
     if (MODE == SRC_CONCAT_UP) {
         const UpCoord u = up_coord(a, y0 - 1, x0 - 1);
@@ -505,23 +568,57 @@ __global__ __launch_bounds__(256, 2) void conv3x3_mfma_kernel(const ConvArgs a)
         __syncthreads();
         STAMP_UP(6);
         const char* const stg = lds_w + stg_off;
-#pragma unroll 2
-        for (int i = tid; i < NCH; i += 256) {
-            const int pix = i >> 2, ch = i & 3;
-            const int py = pix / (TW + 2), px = pix - py * (TW + 2);
-            const int y = y0 - 1 + py, x = x0 - 1 + px;
-            const UpCoord u = up_coord(a, min(max(y, 0), aH - 1), min(max(x, 0), aW - 1));
-            const bool ok = u.ok & (y >= 0) & (y < aH) & (x >= 0) & (x < aW);
-            const int r0 = (u.y0 - lr_y) * LRP, r1 = (u.y1 - lr_y) * LRP;
-            const int c0 = u.x0 - lr_x, c1 = u.x1 - lr_x;
-            const uint4 v00 = *reinterpret_cast<const uint4*>(stg + (r0 + c0) * 64 + ch * 16);
-            const uint4 v01 = *reinterpret_cast<const uint4*>(stg + (r0 + c1) * 64 + ch * 16);
-            const uint4 v10 = *reinterpret_cast<const uint4*>(stg + (r1 + c0) * 64 + ch * 16);
-            const uint4 v11 = *reinterpret_cast<const uint4*>(stg + (r1 + c1) * 64 + ch * 16);
-            uint4 v = chunk_bilerp<T>(v00, v01, v10, v11, u.hx, u.lx, u.hy, u.ly);
-            if (!ok) v = make_uint4(0u, 0u, 0u, 0u);
-            const int row = py * TWP + px;
-            *reinterpret_cast<uint4*>(lds_in + row * 64 + ((ch ^ swz(row)) << 4)) = v;
+        // Column walk: a task is one (pixel column, 16-B chunk) of the in-tile over a segment of
+        // rows.  Going down the column, consecutive output rows share their low-res source rows
+        // (scale < 1/2), so the horizontal interpolation of a low-res row is computed once and
+        // kept in registers; an output row then costs one vertical lerp.  Same arithmetic as
+        // chunk_bilerp, ~3x fewer instructions than interpolating every output independently.
+        constexpr int NE = Elem<T>::NE;
+        for (int tsk = tid; tsk < UP_NSEG * UP_NCOL; tsk += 256) {
+            const int seg = UP_NSEG == 1 ? 0 : tsk / UP_NCOL, col = tsk - seg * UP_NCOL;
+            const int px = col >> 2, ch = col & 3;
+            const int x = x0 - 1 + px;
+            const UpAxis ux = up_axis(min(max(x, 0), aW - 1), a.padL, a.lowW, a.sx);
+            const bool okx = ux.ok & (x >= 0) & (x < aW);
+            const char* const s0 = stg + (ux.i0 - lr_x) * 64 + ch * 16;
+            const char* const s1 = stg + (ux.i1 - lr_x) * 64 + ch * 16;
+            float h0[NE], h1[NE];
+            int cy0 = -1, cy1 = -1;  // low-res rows currently held in h0 / h1
+#pragma unroll
+            for (int i = 0; i < NE; ++i) h0[i] = h1[i] = 0.f;
+            const int pend_row = min(THP, (seg + 1) * UP_SEGR);
+#pragma unroll 1
+            for (int py = seg * UP_SEGR; py < pend_row; ++py) {
+                const int y = y0 - 1 + py;
+                const UpAxis uy = up_axis(min(max(y, 0), aH - 1), a.padT, a.lowH, a.sy);
+                const bool ok = okx & uy.ok & (y >= 0) & (y < aH);
+                if (uy.i0 != cy0) {
+                    if (uy.i0 == cy1) {
+#pragma unroll
+                        for (int i = 0; i < NE; ++i) h0[i] = h1[i];
+                    } else {
+                        const int r = (uy.i0 - lr_y) * (LRP * 64);
+                        chunk_hlerp<T>(*reinterpret_cast<const uint4*>(s0 + r),
+                                       *reinterpret_cast<const uint4*>(s1 + r), ux.h, ux.l, h0);
+                    }
+                    cy0 = uy.i0;
+                }
+                if (uy.i1 != cy1) {
+                    if (uy.i1 == cy0) {
+#pragma unroll
+                        for (int i = 0; i < NE; ++i) h1[i] = h0[i];
+                    } else {
+                        const int r = (uy.i1 - lr_y) * (LRP * 64);
+                        chunk_hlerp<T>(*reinterpret_cast<const uint4*>(s0 + r),
+                                       *reinterpret_cast<const uint4*>(s1 + r), ux.h, ux.l, h1);
+                    }
+                    cy1 = uy.i1;
+                }
+                uint4 v = chunk_vlerp<T>(h0, h1, uy.h, uy.l);
+                if (!ok) v = make_uint4(0u, 0u, 0u, 0u);
+                const int row = py * TWP + px;
+                *reinterpret_cast<uint4*>(lds_in + row * 64 + ((ch ^ swz(row)) << 4)) = v;
+            }
         }
         STAMP_UP(7);
     };
@@ -615,6 +712,9 @@ __global__ __launch_bounds__(256, 2) void conv3x3_mfma_kernel(const ConvArgs a)
         }
     };
     auto gather_plane = [&](int plane, int idle_slot) __attribute__((always_inline)) {
+#ifdef FIUNET_DIAG_NO_GATHER  // timing diagnostic: compute side alone (stale LDS, results are garbage)
+        return;
+#endif
         if constexpr (MODE == SRC_STEM) gather_plane_stem(plane);
         else if (MODE == SRC_DIRECT || plane < p0) gather_plane_dma(plane);
         else gather_plane_up(plane, idle_slot);
@@ -644,21 +744,25 @@ __global__ __launch_bounds__(256, 2) void conv3x3_mfma_kernel(const ConvArgs a)
             const char* wcur = lds_w + (step & 1) * Tile::W_STRIDE + a_off;
 #pragma unroll
             for (int kx = 0; kx < 3; ++kx) {
-                uint4 wa[4], xb[8];
+                uint4 wa[4], xb[NF];
 #pragma unroll
                 for (int m = 0; m < 4; ++m)
                     wa[m] = *reinterpret_cast<const uint4*>(wcur + (kx * BN + m * 16) * 64);
 #pragma unroll
-                for (int n = 0; n < 8; ++n)
+                for (int n = 0; n < NF; ++n)
                     xb[n] = *reinterpret_cast<const uint4*>(
                         lds_in + b_off[kx] + (((n / FR) + ky) * TWP + (n % FR) * 16) * 64);
 #pragma unroll
                 for (int m = 0; m < 4; ++m)
 #pragma unroll
-                    for (int n = 0; n < 8; ++n) mma_chunk<T>(acc[m][n], wa[m], xb[n]);
+                    for (int n = 0; n < NF; ++n) {
+#ifndef FIUNET_DIAG_NO_MFMA  // timing diagnostic: memory side alone (results are garbage)
+                        mma_chunk<T>(acc[m][n], wa[m], xb[n]);
+#endif
+                    }
             }
 #ifdef FIUNET_STAMP
-            asm volatile("" :: "v"(acc[3][7][3]));  // keep the stamp behind the last MFMA
+            asm volatile("" :: "v"(acc[3][NF - 1][3]));  // keep the stamp behind the last MFMA
             __builtin_amdgcn_sched_barrier(0);
 #endif
             STAMP(2);
@@ -691,7 +795,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_mfma_kernel(const ConvArgs a)
     if constexpr (EPI == EPI_SPLITK) {
         float* const slab = a.kslab + (size_t)split * a.B * aH * aW * a.Cout;
 #pragma unroll
-        for (int n = 0; n < 8; ++n) {
+        for (int n = 0; n < NF; ++n) {
             const int y = y0 + wp * ROWS_W + n / FR;
             const int x = x0 + (n % FR) * 16 + l15;
             if (y < aH && x < aW) {
@@ -729,7 +833,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_mfma_kernel(const ConvArgs a)
     char* const pool_img = EPI == EPI_POOL ? (char*)a.pool_dst + (size_t)b * pplane_stride * (a.Cout / PL) +
                                              (size_t)plane0 * pplane_stride + rec_byte : nullptr;
 #pragma unroll
-    for (int n = 0; n < 8; ++n) {
+    for (int n = 0; n < NF; ++n) {
         const int y = y0 + wp * ROWS_W + n / FR;
         const int x = x0 + (n % FR) * 16 + l15;
         const bool ok = (y < aH) && (x < aW);
@@ -786,7 +890,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_mfma_kernel(const ConvArgs a)
         // and n+FR) and the column partner is the neighbouring lane (l15 ^ 1).
         // max(round(a), round(b)) == round(max(a, b)), so this equals pooling the stored tensor.
 #pragma unroll
-        for (int n = 0; n < 8; ++n) {
+        for (int n = 0; n < NF; ++n) {
             if (((n / FR) & 1) != 0) continue;  // upper row of each pair only
             const int y = y0 + wp * ROWS_W + n / FR;
             const int x = x0 + (n % FR) * 16 + l15;
