@@ -28,6 +28,7 @@ OPT_UNFUSED, OPT_KEEP_ALL = 1, 2
 SYMBOLS = (
     "fiunet_abi_version", "fiunet_last_error_string", "fiunet_create", "fiunet_destroy",
     "fiunet_set_options", "fiunet_load_weights", "fiunet_workspace_bytes", "fiunet_forward",
+    "fiunet_forward_strip",
     "fiunet_workspace_bytes_u8", "fiunet_forward_u8", "fiunet_preprocess_u8",
     "fiunet_postprocess_u8", "fiunet_debug_read_activation", "fiunet_profile_enable",
     "fiunet_profile_read",
@@ -69,6 +70,7 @@ def lib() -> ctypes.CDLL:
     L.fiunet_workspace_bytes_u8.argtypes = [vp, ci, ci, ci, ci]
     L.fiunet_workspace_bytes_u8.restype = sz
     L.fiunet_forward.argtypes = [vp, vp, vp, vp, ci, ci, ci, ci, vp, sz, vp]
+    L.fiunet_forward_strip.argtypes = [vp, vp, vp, vp, ci, ci, ci, ci, ci, ci, vp, sz, vp]
     L.fiunet_forward_u8.argtypes = [vp, vp, vp, vp, ci, ci, ci, ci, vp, sz, vp]
     L.fiunet_preprocess_u8.argtypes = [vp, vp, sz, vp]
     L.fiunet_postprocess_u8.argtypes = [vp, vp, sz, vp]
@@ -143,6 +145,14 @@ class Context:
         check(lib().fiunet_forward(self._h, f1.data_ptr(), f2.data_ptr(), out.data_ptr(), b, h, w,
                                    precision, workspace.data_ptr(), workspace.numel(), s),
               "fiunet_forward")
+
+    def forward_strip(self, f1, f2, out, y_origin, h_image, precision, workspace, stream=None):
+        """The forward on rows [y_origin, y_origin + h) of an image of h_image rows."""
+        b, _, h, w = f1.shape
+        s = torch.cuda.current_stream(f1.device).cuda_stream if stream is None else stream
+        check(lib().fiunet_forward_strip(self._h, f1.data_ptr(), f2.data_ptr(), out.data_ptr(), b, h,
+                                         w, y_origin, h_image, precision, workspace.data_ptr(),
+                                         workspace.numel(), s), "fiunet_forward_strip")
 
     def forward_u8(self, f1, f2, out, precision, workspace, stream=None):
         b, _, h, w = f1.shape

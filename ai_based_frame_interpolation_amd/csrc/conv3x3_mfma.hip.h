@@ -70,6 +70,10 @@ struct ConvArgs {
     int lowH, lowW;      // CONCAT_UP: spatial size of src1
     int padT, padL;      // CONCAT_UP: F.pad top/left (unet.py:52-53)
     float sy, sx;        // CONCAT_UP: (low-1)/(2*low-1), align_corners=True scale
+    // CONCAT_UP on a horizontal band of a taller image (fiunet_forward_strip); un-tiled: 0, 0, lowH
+    int upOffY;          //   global row of this tensor's row 0
+    int lowOffY;         //   global row of src1's row 0
+    int lowHg;           //   rows of the WHOLE image's low-res tensor (padT, sy are global too)
     int tilesX, tilesY, nct;
     int relu;
     const void* zero_page; // >= 64 zero bytes: LDS-DMA source for padding pixels
@@ -218,24 +222,40 @@ __device__ __forceinline__ uint4 ldg16(const char* p) { return *reinterpret_cast
 // Bilinear x2 (align_corners=True) source coordinates and weights of one upsampled+padded pixel
 // (unet.py:40,49-53), shared by every kernel that upsamples so they agree bit for bit.
 struct UpAxis {
-    int i0, i1;   // low-res source indices
+    int i0, i1;   // low-res source indices (local to the tensor at hand)
     float h, l;   // weights of i0, i1
     bool ok;      // inside the upsampled extent (false: F.pad zero)
 };
-// one axis of the mapping: c = conv-input coordinate (already clamped to the image)
-__device__ __forceinline__ UpAxis up_axis(int c, int pad, int lowN, float scale)
+// One axis of the mapping.  c = conv-input coordinate (already clamped to the local tensor).
+// Strip-tiled forwards (fiunet_forward_strip) run on a horizontal band of a taller image: the
+// mapping is then evaluated in GLOBAL coordinates (c + off; low-res extent lowNg; pad and scale of
+// the whole image) and only the resulting source indices are moved back into the band (- lowOff,
+// clamped to its lowN rows), so a band computes exactly what the whole image would.  Un-tiled:
+// off = lowOff = 0 and lowNg = lowN.
+__device__ __forceinline__ UpAxis up_axis(int c, int off, int pad, int lowNg, float scale, int lowOff,
+                                          int lowN)
 {
     UpAxis u;
-    int cu = c - pad;
-    u.ok = (cu >= 0) & (cu < 2 * lowN);
-    cu = min(max(cu, 0), 2 * lowN - 1);
+    int cu = c + off - pad;
+    u.ok = (cu >= 0) & (cu < 2 * lowNg);
+    cu = min(max(cu, 0), 2 * lowNg - 1);
     // f is the ROUNDED product, as in aten (the library is built with -ffp-contract=off)
     const float f = scale * (float)cu;
-    u.i0 = (int)f;
-    u.i1 = u.i0 < lowN - 1 ? u.i0 + 1 : u.i0;
-    u.l = f - (float)u.i0;
+    const int g0 = (int)f;
+    const int g1 = g0 < lowNg - 1 ? g0 + 1 : g0;
+    u.l = f - (float)g0;
     u.h = 1.0f - u.l;
+    u.i0 = min(max(g0 - lowOff, 0), lowN - 1);
+    u.i1 = min(max(g1 - lowOff, 0), lowN - 1);
     return u;
+}
+__device__ __forceinline__ UpAxis up_axis_y(const ConvArgs& a, int y)
+{
+    return up_axis(y, a.upOffY, a.padT, a.lowHg, a.sy, a.lowOffY, a.lowH);
+}
+__device__ __forceinline__ UpAxis up_axis_x(const ConvArgs& a, int x)
+{
+    return up_axis(x, 0, a.padL, a.lowW, a.sx, 0, a.lowW);
 }
 struct UpCoord {
     int y0, y1, x0, x1;
@@ -244,7 +264,7 @@ struct UpCoord {
 };
 __device__ __forceinline__ UpCoord up_coord(const ConvArgs& a, int y, int x)
 {
-    const UpAxis v = up_axis(y, a.padT, a.lowH, a.sy), h = up_axis(x, a.padL, a.lowW, a.sx);
+    const UpAxis v = up_axis_y(a, y), h = up_axis_x(a, x);
     UpCoord u;
     u.y0 = v.i0; u.y1 = v.i1; u.hy = v.h; u.ly = v.l;
     u.x0 = h.i0; u.x1 = h.i1; u.hx = h.h; u.lx = h.l;
@@ -578,7 +598,7 @@ __global__ __launch_bounds__(256, conv_occupancy(BN, TH, TW)) void conv3x3_mfma_
             const int seg = UP_NSEG == 1 ? 0 : tsk / UP_NCOL, col = tsk - seg * UP_NCOL;
             const int px = col >> 2, ch = col & 3;
             const int x = x0 - 1 + px;
-            const UpAxis ux = up_axis(min(max(x, 0), aW - 1), a.padL, a.lowW, a.sx);
+            const UpAxis ux = up_axis_x(a, min(max(x, 0), aW - 1));
             const bool okx = ux.ok & (x >= 0) & (x < aW);
             const char* const s0 = stg + (ux.i0 - lr_x) * 64 + ch * 16;
             const char* const s1 = stg + (ux.i1 - lr_x) * 64 + ch * 16;
@@ -590,7 +610,7 @@ __global__ __launch_bounds__(256, conv_occupancy(BN, TH, TW)) void conv3x3_mfma_
 #pragma unroll 1
             for (int py = seg * UP_SEGR; py < pend_row; ++py) {
                 const int y = y0 - 1 + py;
-                const UpAxis uy = up_axis(min(max(y, 0), aH - 1), a.padT, a.lowH, a.sy);
+                const UpAxis uy = up_axis_y(a, min(max(y, 0), aH - 1));
                 const bool ok = okx & uy.ok & (y >= 0) & (y < aH);
                 if (uy.i0 != cy0) {
                     if (uy.i0 == cy1) {

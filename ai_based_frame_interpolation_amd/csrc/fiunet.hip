@@ -269,10 +269,14 @@ template <typename T> int launch_conv(const ConvArgs& a, int mode, int epi, hipS
 
 inline unsigned grid_for(size_t n) { return (unsigned)std::min<size_t>((n + 255) / 256, 256 * 32); }
 
+// The band [y_origin, y_origin + H) of an image of Hg rows (un-tiled: y_origin = 0, Hg = H).
 template <typename T>
 int forward_impl(fiunet_ctx* ctx, const float* f1, const float* f2, float* out, int B, int H,
-                 int W, char* ws, const Plan& p, hipStream_t s)
+                 int W, char* ws, const Plan& p, hipStream_t s, int y_origin, int Hg)
 {
+    int hg[5];  // rows of the whole image at each pyramid level (floor halving, unet.py:28)
+    hg[0] = Hg;
+    for (int l = 1; l < 5; ++l) hg[l] = hg[l - 1] / 2;
     const bool bf16 = sizeof(T) == 2;
     const bool unfused = ctx->flags & FIUNET_OPT_UNFUSED;
     auto act = [&](int i) { return (T*)(ws + p.act_off[i]); };
@@ -352,10 +356,15 @@ int forward_impl(fiunet_ctx* ctx, const float* f1, const float* f2, float* out, 
             a.src1 = act(kSrc1[i]);
             a.C1 = kCout[kSrc1[i]];
             a.lowH = p.hs[lv + 1]; a.lowW = p.ws[lv + 1];
-            const int dy = a.H - 2 * a.lowH, dx = a.W - 2 * a.lowW;  // unet.py:49-53
+            // vertical mapping in whole-image coordinates (a band starts at a multiple of 16 rows,
+            // so its level-l tensors start at global row y_origin >> l)
+            a.lowHg = hg[lv + 1];
+            a.upOffY = y_origin >> lv;
+            a.lowOffY = y_origin >> (lv + 1);
+            const int dy = hg[lv] - 2 * a.lowHg, dx = a.W - 2 * a.lowW;  // unet.py:49-53
             a.padT = dy / 2; a.padL = dx / 2;
             // aten area_pixel_compute_scale, align_corners=True: (in - 1) / (out - 1) in fp32
-            a.sy = 2 * a.lowH > 1 ? (float)(a.lowH - 1) / (float)(2 * a.lowH - 1) : 0.f;
+            a.sy = 2 * a.lowHg > 1 ? (float)(a.lowHg - 1) / (float)(2 * a.lowHg - 1) : 0.f;
             a.sx = 2 * a.lowW > 1 ? (float)(a.lowW - 1) / (float)(2 * a.lowW - 1) : 0.f;
         }
         if (a.C0 + a.C1 != cw.cin) return fail(FIUNET_ERR_INVALID_ARG, "internal: channel plan mismatch");
@@ -574,8 +583,20 @@ int fiunet_forward(fiunet_ctx* ctx, const float* frame1, const float* frame2, fl
                    int H, int W, int precision, void* workspace, size_t workspace_bytes,
                    void* stream)
 {
+    return fiunet_forward_strip(ctx, frame1, frame2, out, B, H, W, 0, H, precision, workspace,
+                                workspace_bytes, stream);
+}
+
+int fiunet_forward_strip(fiunet_ctx* ctx, const float* frame1, const float* frame2, float* out, int B,
+                         int H, int W, int y_origin, int H_image, int precision, void* workspace,
+                         size_t workspace_bytes, void* stream)
+{
     if (!ctx || !frame1 || !frame2 || !out || !workspace)
         return fail(FIUNET_ERR_INVALID_ARG, "NULL argument");
+    if (y_origin < 0 || y_origin % 16 != 0 || H_image < H || y_origin > H_image - H)
+        return fail(FIUNET_ERR_BAD_SHAPE, "strip: y_origin must be a multiple of 16 inside the image");
+    if (y_origin + H != H_image && H % 16 != 0)
+        return fail(FIUNET_ERR_BAD_SHAPE, "strip: rows must be a multiple of 16 unless it ends the image");
     if (!ctx->loaded) return fail(FIUNET_ERR_NOT_LOADED, "fiunet_forward before fiunet_load_weights");
     if (precision != FIUNET_FP32 && precision != FIUNET_BF16)
         return fail(FIUNET_ERR_INVALID_ARG, "bad precision");
@@ -589,8 +610,9 @@ int fiunet_forward(fiunet_ctx* ctx, const float* frame1, const float* frame2, fl
     HIP_TRY(hipSetDevice(ctx->device));
     hipStream_t s = (hipStream_t)stream;
     if (precision == FIUNET_BF16)
-        return forward_impl<__bf16>(ctx, frame1, frame2, out, B, H, W, (char*)workspace, p, s);
-    return forward_impl<float>(ctx, frame1, frame2, out, B, H, W, (char*)workspace, p, s);
+        return forward_impl<__bf16>(ctx, frame1, frame2, out, B, H, W, (char*)workspace, p, s, y_origin,
+                                    H_image);
+    return forward_impl<float>(ctx, frame1, frame2, out, B, H, W, (char*)workspace, p, s, y_origin, H_image);
 }
 
 size_t fiunet_workspace_bytes_u8(const fiunet_ctx* ctx, int B, int H, int W, int precision)

@@ -1,0 +1,132 @@
+"""Spatial tiling of one large frame pair into horizontal strips.
+
+The reference has no tiling code; a frame pair is one forward (model/unet.py:84-95).  For frames
+whose latency matters (2160x3840) the forward is cut into `n` row bands, one per GPU.  Facts the
+plan rests on (measured on the reference): an output pixel depends on inputs within
++-109 pixels; the encoder floor-halves the grid four times; the decoder upsamples with
+align_corners=True, i.e. with a scale that depends on the WHOLE image's size.  Hence:
+
+  * bands start at multiples of 16 rows, so the band's pyramid is a window of the image's pyramid;
+  * each band carries a halo of 112 input rows (>= 109, multiple of 16) on every cut edge and the
+    halo's output rows are discarded ("one-shot input halo", SURVEY 8e option B: the halo is 1-channel
+    input, 2 x 112 x W x 4 B per cut, instead of ~22 per-layer exchanges of 64-1024-channel rows);
+  * the kernels evaluate the upsample mapping and the F.pad offsets in whole-image coordinates
+    (`fiunet_forward_strip`), so the kept rows are the un-tiled result - bit for bit wherever the
+    kernels take the same path (the split-K of very small problems can differ; see the tests).
+
+Multi-GPU: one process per GPU, rank r computes band r.  The only traffic is the scatter of the
+input bands (+halo) from the rank that holds the frames and the gather of the output bands, as
+point-to-point send/recv (RCCL over the direct xGMI links on GPUs, gloo in the CPU tests); there is
+no collective and no exchange inside the forward.
+"""
+from __future__ import annotations
+
+from typing import Callable, List, NamedTuple, Optional
+
+import torch
+import torch.distributed as dist
+
+HALO = 112   # rows; >= the 109-pixel receptive-field radius, multiple of 16
+ALIGN = 16   # four 2x2 max-pools
+
+
+class Strip(NamedTuple):
+    core0: int  # first output row this strip is responsible for
+    core1: int  # one past its last output row
+    ext0: int   # first input row it needs (core0 - halo, clipped to the image)
+    ext1: int   # one past the last input row it needs
+
+
+def strip_plan(height: int, n_strips: int, halo: int = HALO) -> List[Strip]:
+    """Cut `height` rows into `n_strips` bands of near-equal size with origins at multiples of 16
+    (2160 rows, 4 strips -> origins 0/544/1088/1632 as in SURVEY 8d config 5).  Trailing strips may
+    be empty (core0 == core1) when the image has fewer 16-row groups than strips."""
+    if height < ALIGN:
+        raise ValueError(f"image height {height} < {ALIGN}")
+    if halo % ALIGN or halo < 109:
+        raise ValueError("halo must be a multiple of 16 and cover the 109-row receptive field")
+    groups = -(-height // ALIGN)                 # 16-row groups, the last may be partial
+    per = -(-groups // n_strips)
+    plan = []
+    for i in range(n_strips):
+        c0 = min(i * per * ALIGN, height)
+        c1 = min((i + 1) * per * ALIGN, height)
+        e0 = max(c0 - halo, 0)
+        e1 = min(c1 + halo, height)
+        plan.append(Strip(c0, c1, e0, e1))
+    return plan
+
+
+StripFn = Callable[[torch.Tensor, torch.Tensor, int, int], torch.Tensor]
+
+
+def forward_tiled(strip_fn: StripFn, frame1: torch.Tensor, frame2: torch.Tensor, n_strips: int,
+                  halo: int = HALO) -> torch.Tensor:
+    """All strips on this device, one after the other (bounds the workspace of a huge frame to one
+    band's; also the single-GPU check of the multi-GPU path).  `strip_fn(f1_band, f2_band, y_origin,
+    image_height)` is `FrameInterpolationUNet.forward_strip`."""
+    h = frame1.shape[-2]
+    out = torch.empty_like(frame1)
+    for s in strip_plan(h, n_strips, halo):
+        if s.core1 <= s.core0:
+            continue
+        band = strip_fn(frame1[..., s.ext0:s.ext1, :].contiguous(),
+                        frame2[..., s.ext0:s.ext1, :].contiguous(), s.ext0, h)
+        out[..., s.core0:s.core1, :] = band[..., s.core0 - s.ext0:s.core1 - s.ext0, :]
+    return out
+
+
+def _p2p(ops):
+    if ops:
+        for w in dist.batch_isend_irecv(ops):
+            w.wait()
+
+
+def forward_tiled_distributed(strip_fn: StripFn, frame1: Optional[torch.Tensor],
+                              frame2: Optional[torch.Tensor], shape, device, root: int = 0,
+                              halo: int = HALO, group=None) -> Optional[torch.Tensor]:
+    """Rank `root` holds the fp32 pair `[B, C, H, W]` (`shape`); rank r computes strip r of
+    world_size strips; `root` returns the assembled `[B, C, H, W]` output, the others None."""
+    rank, world = dist.get_rank(group), dist.get_world_size(group)
+    b, c, h, w = shape
+    plan = strip_plan(h, world, halo)
+    mine = plan[rank]
+    # 1. input bands (+halo): root -> ranks
+    if rank == root:
+        ops = []
+        for r, s in enumerate(plan):
+            if r != root and s.core1 > s.core0:
+                ops.append(dist.P2POp(dist.isend, frame1[..., s.ext0:s.ext1, :].contiguous(), r, group))
+                ops.append(dist.P2POp(dist.isend, frame2[..., s.ext0:s.ext1, :].contiguous(), r, group))
+        _p2p(ops)
+        f1 = frame1[..., mine.ext0:mine.ext1, :].contiguous()
+        f2 = frame2[..., mine.ext0:mine.ext1, :].contiguous()
+    elif mine.core1 > mine.core0:
+        f1 = torch.empty((b, c, mine.ext1 - mine.ext0, w), dtype=torch.float32, device=device)
+        f2 = torch.empty_like(f1)
+        _p2p([dist.P2POp(dist.irecv, f1, root, group), dist.P2POp(dist.irecv, f2, root, group)])
+    # 2. this rank's band
+    core = None
+    if mine.core1 > mine.core0:
+        band = strip_fn(f1, f2, mine.ext0, h)
+        core = band[..., mine.core0 - mine.ext0:mine.core1 - mine.ext0, :].contiguous()
+    # 3. output bands: ranks -> root
+    if rank != root:
+        if core is not None:
+            _p2p([dist.P2POp(dist.isend, core, root, group)])
+        return None
+    out = torch.empty((b, c, h, w), dtype=torch.float32, device=device)
+    ops, bufs = [], []
+    for r, s in enumerate(plan):
+        if s.core1 <= s.core0:
+            continue
+        if r == root:
+            out[..., s.core0:s.core1, :] = core
+        else:
+            buf = torch.empty((b, c, s.core1 - s.core0, w), dtype=torch.float32, device=device)
+            bufs.append((s, buf))
+            ops.append(dist.P2POp(dist.irecv, buf, r, group))
+    _p2p(ops)
+    for s, buf in bufs:
+        out[..., s.core0:s.core1, :] = buf
+    return out

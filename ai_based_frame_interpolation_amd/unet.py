@@ -184,6 +184,24 @@ class FrameInterpolationUNet(nn.Module):
         return out if in_dtype == torch.float32 else out.to(in_dtype)
 
     @torch.no_grad()
+    def forward_strip(self, frame1: torch.Tensor, frame2: torch.Tensor, y_origin: int,
+                      image_height: int) -> torch.Tensor:
+        """The same forward on the band of rows [y_origin, y_origin + H) of a taller image
+        (spatial tiling): upsampling and F.pad are evaluated in whole-image
+        coordinates, so rows at least 112 away from a cut edge equal the un-tiled result.  See
+        tiling.py for the strip plan; `fiunet_forward_strip` in include/fiunet.h for the rules."""
+        self._check_pair(frame1, frame2, (torch.float32,))
+        f1, f2 = frame1.contiguous(), frame2.contiguous()
+        b, _, h, w = f1.shape
+        prec = _PRECISIONS[self.precision]
+        ctx = self._context(f1.device)
+        ws = self._workspace(ctx, f1.device, b, h, w, prec)
+        out = torch.empty_like(f1)
+        with torch.cuda.device(f1.device):
+            ctx.forward_strip(f1, f2, out, int(y_origin), int(image_height), prec, ws)
+        return out
+
+    @torch.no_grad()
     def forward_u8(self, frame1: torch.Tensor, frame2: torch.Tensor) -> torch.Tensor:
         """uint8 [B,C,H,W] frames in -> uint8 interpolated frame, with the reference's
         pre/post-processing (inference.py:31-35, :54-61) on device."""

@@ -21,7 +21,7 @@
 extern "C" {
 #endif
 
-#define FIUNET_ABI_VERSION 1
+#define FIUNET_ABI_VERSION 2
 
 enum fiunet_status {
     FIUNET_OK = 0,
@@ -79,6 +79,20 @@ size_t fiunet_workspace_bytes(const fiunet_ctx* ctx, int B, int H, int W, int pr
 int fiunet_forward(fiunet_ctx* ctx, const float* frame1, const float* frame2, float* out, int B,
                    int H, int W, int precision, void* workspace, size_t workspace_bytes,
                    void* stream);
+
+/* Spatial tiling (2160x3840 pairs cut into horizontal strips, one per
+ * GPU).  The reference has no counterpart: it is the same forward (model/unet.py:84-95) evaluated on
+ * the band of rows [y_origin, y_origin + H) of an image of H_image rows.  frame1, frame2, out are that
+ * band only ([B, C, H, W] contiguous).  The align_corners=True upsampling (unet.py:40) and the F.pad
+ * offsets (unet.py:49-53) are evaluated in whole-image coordinates, so every output row whose
+ * receptive field (+-109 rows) lies inside the band - or is cut only by a true image border - equals
+ * the un-tiled result; rows nearer to a cut edge see zero padding there and must be discarded by the
+ * caller (use a halo of >= 112 rows).  y_origin must be a multiple of 16 (four 2x2 max-pools) and H a
+ * multiple of 16 unless the band ends the image.  fiunet_forward(..., H, ...) is the band
+ * y_origin = 0, H_image = H.  Workspace: fiunet_workspace_bytes(ctx, B, H, W, precision). */
+int fiunet_forward_strip(fiunet_ctx* ctx, const float* frame1, const float* frame2, float* out, int B,
+                         int H, int W, int y_origin, int H_image, int precision, void* workspace,
+                         size_t workspace_bytes, void* stream);
 
 /* Video-path variant: uint8 frames in, uint8 interpolated frame out, with the reference's
  * pre/post-processing fused on device: x/255*2-1 (model/inference.py:31-35) and

@@ -57,3 +57,82 @@ def test_sharded_video_world2(n_frames):
         p.join(120)
         assert p.exitcode == 0
     assert q.get(timeout=5) is True
+
+
+# ---- spatial tiling (tiling.py): strips + halo, world_size 2 ------------------------------------
+from ai_based_frame_interpolation_amd import tiling  # noqa: E402
+
+_RADIUS = 109  # the network's receptive-field radius
+
+
+def _box_strip_fn(f1, f2, y_origin, image_h):
+    """Stand-in with the network's locality: vertical box sum of radius 109 with zero padding at
+    the band's edges, plus a term in the GLOBAL row index.  Rows >= 109 away from a cut edge equal
+    the whole-image result, exactly like the conv stack."""
+    x = (f1 + 2 * f2).double()
+    h = x.shape[-2]
+    c = torch.cat([torch.zeros_like(x[..., :1, :]), x.cumsum(-2)], dim=-2)
+    idx = torch.arange(h)
+    hi = (idx + _RADIUS + 1).clamp(max=h)
+    lo = (idx - _RADIUS).clamp(min=0)
+    box = c[..., hi, :] - c[..., lo, :]
+    rows = (y_origin + idx).double().view(-1, 1) / image_h
+    return (box + rows).float()
+
+
+def test_strip_plan_matches_survey_config5():
+    plan = tiling.strip_plan(2160, 4)
+    assert [s.core0 for s in plan] == [0, 544, 1088, 1632]
+    assert plan[-1].core1 == 2160 and plan[0].ext0 == 0 and plan[-1].ext1 == 2160
+    for s in plan:
+        assert s.ext0 % 16 == 0 and (s.ext1 % 16 == 0 or s.ext1 == 2160)
+        assert s.core0 - s.ext0 in (0, 112) and s.ext1 - s.core1 in (0, 112)
+    # cores tile the image exactly once, also for ragged heights and more strips than groups
+    for h, n in ((1080, 4), (1080, 8), (135, 3), (17, 4), (16, 2)):
+        plan = tiling.strip_plan(h, n)
+        rows = [r for s in plan for r in range(s.core0, s.core1)]
+        assert rows == list(range(h))
+        assert all(s.core0 % 16 == 0 for s in plan if s.core1 > s.core0)
+
+
+@pytest.mark.parametrize("h,n", [(640, 4), (1080, 3), (200, 2)])
+def test_forward_tiled_single_process(h, n):
+    g = torch.Generator().manual_seed(3)
+    f1 = torch.rand(2, 1, h, 12, generator=g)
+    f2 = torch.rand(2, 1, h, 12, generator=g)
+    want = _box_strip_fn(f1, f2, 0, h)
+    got = tiling.forward_tiled(_box_strip_fn, f1, f2, n)
+    assert torch.equal(got, want)
+
+
+def _tile_worker(rank, world, port, h, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        g = torch.Generator().manual_seed(9)
+        shape = (1, 1, h, 20)
+        f1 = torch.rand(shape, generator=g)
+        f2 = torch.rand(shape, generator=g)
+        out = tiling.forward_tiled_distributed(_box_strip_fn, f1 if rank == 0 else None,
+                                               f2 if rank == 0 else None, shape, torch.device("cpu"))
+        if rank == 0:
+            q.put(bool(torch.equal(out, _box_strip_fn(f1, f2, 0, h))))
+        else:
+            assert out is None
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("h", [16, 544, 1080])
+def test_tiled_forward_world2(h):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_tile_worker, args=(r, 2, port, h, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    assert q.get(timeout=5) is True
