@@ -31,7 +31,7 @@ SYMBOLS = (
     "fiunet_forward_strip",
     "fiunet_workspace_bytes_u8", "fiunet_forward_u8", "fiunet_preprocess_u8",
     "fiunet_postprocess_u8", "fiunet_debug_read_activation", "fiunet_profile_enable",
-    "fiunet_profile_read",
+    "fiunet_profile_read", "fiunet_metrics_workspace_bytes", "fiunet_psnr_u8", "fiunet_ssim_u8",
 )
 
 _lib = None
@@ -76,6 +76,10 @@ def lib() -> ctypes.CDLL:
     L.fiunet_postprocess_u8.argtypes = [vp, vp, sz, vp]
     L.fiunet_debug_read_activation.argtypes = [vp, vp, ci, ci, ci, ci, ci, vp,
                                                ctypes.POINTER(ci), vp]
+    L.fiunet_metrics_workspace_bytes.argtypes = [ci, ci, ci]
+    L.fiunet_metrics_workspace_bytes.restype = sz
+    L.fiunet_psnr_u8.argtypes = [vp, vp, ci, ci, ci, vp, vp, sz, vp]
+    L.fiunet_ssim_u8.argtypes = [vp, vp, ci, ci, ci, vp, vp, sz, vp]
     L.fiunet_profile_enable.argtypes = [vp, ci]
     L.fiunet_profile_read.argtypes = [vp, ctypes.POINTER(ci), ctypes.POINTER(ctypes.c_float),
                                       ctypes.POINTER(ctypes.c_double), ctypes.c_char_p, ci]

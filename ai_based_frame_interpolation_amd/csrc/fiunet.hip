@@ -9,6 +9,7 @@
 // gfx950 only; no CPU fallback: every entry point either launches HIP kernels or returns an error.
 #include "../../include/fiunet.h"
 #include "pointwise.hip.h"
+#include "metrics.hip.h"
 
 #include <algorithm>
 #include <cmath>
@@ -641,6 +642,68 @@ int fiunet_forward_u8(fiunet_ctx* ctx, const uint8_t* frame1, const uint8_t* fra
     if ((rc = fiunet_preprocess_u8(frame2, b, n, stream))) return rc;
     if ((rc = fiunet_forward(ctx, a, b, o, B, H, W, precision, workspace, base, stream))) return rc;
     return fiunet_postprocess_u8(o, out, n, stream);
+}
+
+static inline int ssim_tiles(int H, int W, int* tiles_x)
+{
+    const int ow = W - 2 * SSIM_PAD, oh = H - 2 * SSIM_PAD;
+    const int tx = (ow + SSIM_TX - 1) / SSIM_TX, ty = (oh + SSIM_TY - 1) / SSIM_TY;
+    if (tiles_x) *tiles_x = tx;
+    return tx * ty;
+}
+
+size_t fiunet_metrics_workspace_bytes(int images, int H, int W)
+{
+    if (images < 1 || H < 1 || W < 1) {
+        g_err = "fiunet_metrics_workspace_bytes: bad arguments";
+        return 0;
+    }
+    const size_t tiles = (H >= SSIM_WIN && W >= SSIM_WIN) ? (size_t)ssim_tiles(H, W, nullptr) : 0;
+    return align256((size_t)images * 8) + align256((size_t)images * tiles * 8);
+}
+
+int fiunet_psnr_u8(const uint8_t* pred, const uint8_t* target, int images, int H, int W, double* out,
+                   void* workspace, size_t workspace_bytes, void* stream)
+{
+    if (!pred || !target || !out || !workspace) return fail(FIUNET_ERR_INVALID_ARG, "NULL argument");
+    if (images < 1 || H < 1 || W < 1) return fail(FIUNET_ERR_BAD_SHAPE, "bad image shape");
+    if (images > 65535) return fail(FIUNET_ERR_INVALID_ARG, "more than 65535 planes per call");
+    if (workspace_bytes < align256((size_t)images * 8)) return fail(FIUNET_ERR_WORKSPACE, "workspace too small");
+    if ((uintptr_t)workspace & 255) return fail(FIUNET_ERR_INVALID_ARG, "workspace not 256-B aligned");
+    hipStream_t s = (hipStream_t)stream;
+    unsigned long long* sums = (unsigned long long*)workspace;
+    const size_t n = (size_t)H * W;
+    HIP_TRY(hipMemsetAsync(sums, 0, (size_t)images * 8, s));
+    const unsigned bx = (unsigned)std::min<size_t>((n / 16 + 255) / 256 + 1, 1024);
+    hipLaunchKernelGGL(sqdiff_u8_kernel, dim3(bx, (unsigned)images), dim3(256), 0, s, pred, target, n, sums);
+    HIP_TRY(hipGetLastError());
+    hipLaunchKernelGGL(psnr_finalize_kernel, dim3((images + 63) / 64), dim3(64), 0, s, sums, n, out, images);
+    HIP_TRY(hipGetLastError());
+    return FIUNET_OK;
+}
+
+int fiunet_ssim_u8(const uint8_t* pred, const uint8_t* target, int images, int H, int W, double* out,
+                   void* workspace, size_t workspace_bytes, void* stream)
+{
+    if (!pred || !target || !out || !workspace) return fail(FIUNET_ERR_INVALID_ARG, "NULL argument");
+    if (images < 1) return fail(FIUNET_ERR_BAD_SHAPE, "bad image shape");
+    if (H < SSIM_WIN || W < SSIM_WIN)
+        return fail(FIUNET_ERR_BAD_SHAPE, "SSIM: the 7x7 window exceeds the image (skimage raises too)");
+    if (images > 65535) return fail(FIUNET_ERR_INVALID_ARG, "more than 65535 planes per call");
+    if (workspace_bytes < fiunet_metrics_workspace_bytes(images, H, W))
+        return fail(FIUNET_ERR_WORKSPACE, "workspace too small");
+    if ((uintptr_t)workspace & 255) return fail(FIUNET_ERR_INVALID_ARG, "workspace not 256-B aligned");
+    hipStream_t s = (hipStream_t)stream;
+    int tx = 0;
+    const int tiles = ssim_tiles(H, W, &tx);
+    double* partial = (double*)((char*)workspace + align256((size_t)images * 8));
+    hipLaunchKernelGGL(ssim_u8_kernel, dim3((unsigned)tiles, (unsigned)images), dim3(256), 0, s, pred, target,
+                       H, W, tx, partial);
+    HIP_TRY(hipGetLastError());
+    const double count = (double)(H - 2 * SSIM_PAD) * (double)(W - 2 * SSIM_PAD);
+    hipLaunchKernelGGL(ssim_finalize_kernel, dim3((unsigned)images), dim3(256), 0, s, partial, tiles, count, out);
+    HIP_TRY(hipGetLastError());
+    return FIUNET_OK;
 }
 
 int fiunet_preprocess_u8(const uint8_t* in, float* out, size_t n, void* stream)

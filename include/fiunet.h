@@ -109,6 +109,21 @@ int fiunet_preprocess_u8(const uint8_t* in, float* out, size_t n, void* stream);
 /* Replaces postprocess_image's arithmetic (model/inference.py:54-61), truncating cast. */
 int fiunet_postprocess_u8(const float* in, uint8_t* out, size_t n, void* stream);
 
+/* Quality metrics of the evaluation loop on device.  The reference computes
+ * them on the host with scikit-image, one frame at a time (model/evaluation.py:194-218,
+ * model/evaluation_simple.py:134-156): peak_signal_noise_ratio(target, pred, data_range=255) and
+ * structural_similarity(target, pred, data_range=255) with skimage's defaults (7x7 uniform window,
+ * sample covariance, K1 = 0.01, K2 = 0.03, mean over the image minus a 3-pixel border).
+ * pred, target: device uint8, `images` planes of H x W (e.g. the [B, C, H, W] output of
+ * fiunet_forward_u8 and the ground-truth frames); out: device double[images] (+inf PSNR for identical
+ * planes, as skimage).  workspace: device scratch of fiunet_metrics_workspace_bytes(images, H, W),
+ * 256-B aligned.  SSIM needs H, W >= 7.  Asynchronous on `stream`. */
+size_t fiunet_metrics_workspace_bytes(int images, int H, int W);
+int fiunet_psnr_u8(const uint8_t* pred, const uint8_t* target, int images, int H, int W, double* out,
+                   void* workspace, size_t workspace_bytes, void* stream);
+int fiunet_ssim_u8(const uint8_t* pred, const uint8_t* target, int images, int H, int W, double* out,
+                   void* workspace, size_t workspace_bytes, void* stream);
+
 /* Parity-test hook: after a fiunet_forward on `workspace`, convert one intermediate activation
  * (NHWC in the compute precision) to fp32 NCHW at dst.  tap = 2*block + conv for the 18 fused
  * conv+BN+ReLU stages in state-dict order (0 = unet.inc.double_conv.0 ... 17 =

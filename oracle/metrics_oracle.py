@@ -1,0 +1,65 @@
+"""TEST INFRASTRUCTURE ONLY (see oracle/unet_oracle.py's header): CPU restatement of the two
+image-quality metrics the reference's evaluators call on the uint8 frames
+(/root/reference/model/evaluation.py:194-218, evaluation_simple.py:134-156):
+
+    psnr(target, pred, data_range=255)   # skimage.metrics.peak_signal_noise_ratio
+    ssim(target, pred, data_range=255)   # skimage.metrics.structural_similarity
+
+scikit-image is a third-party dependency of the reference (`requirements.txt:8`, UNPINNED) and is
+not installed in this image, and the reference holds no golden PSNR/SSIM values, so this restatement
+follows skimage's published algorithm (structural_similarity with its defaults: win_size 7,
+uniform filter = scipy.ndimage.uniform_filter, use_sample_covariance=True, K1 0.01, K2 0.03, mean of
+the map cropped by (win_size-1)//2) and is pinned only by `ssim_bruteforce` below, an independent
+pure-Python evaluation of the SSIM definition on small images: **parity unpinned against skimage
+itself**.  Only tests/ may import this module.
+"""
+from __future__ import annotations
+
+import numpy as np
+from scipy import ndimage
+
+
+def psnr_u8(pred: np.ndarray, target: np.ndarray) -> float:
+    err = np.mean((target.astype(np.float64) - pred.astype(np.float64)) ** 2, dtype=np.float64)
+    if err == 0:
+        return float("inf")
+    return float(10.0 * np.log10((255.0 ** 2) / err))
+
+
+def ssim_u8(pred: np.ndarray, target: np.ndarray, win: int = 7) -> float:
+    """structural_similarity(target, pred, data_range=255) for 2-D uint8 images."""
+    if min(pred.shape) < win:
+        raise ValueError("win_size exceeds image extent")
+    x = target.astype(np.float64)
+    y = pred.astype(np.float64)
+    npix = win * win
+    cov_norm = npix / (npix - 1.0)
+    f = lambda im: ndimage.uniform_filter(im, size=win)
+    ux, uy = f(x), f(y)
+    uxx, uyy, uxy = f(x * x), f(y * y), f(x * y)
+    vx = cov_norm * (uxx - ux * ux)
+    vy = cov_norm * (uyy - uy * uy)
+    vxy = cov_norm * (uxy - ux * uy)
+    c1, c2 = (0.01 * 255.0) ** 2, (0.03 * 255.0) ** 2
+    s = ((2 * ux * uy + c1) * (2 * vxy + c2)) / ((ux ** 2 + uy ** 2 + c1) * (vx + vy + c2))
+    pad = (win - 1) // 2
+    return float(s[pad:s.shape[0] - pad, pad:s.shape[1] - pad].mean(dtype=np.float64))
+
+
+def ssim_bruteforce(pred: np.ndarray, target: np.ndarray, win: int = 7) -> float:
+    """The definition, window by window, exact rational window statistics (small images only)."""
+    h, w = pred.shape
+    c1, c2 = (0.01 * 255.0) ** 2, (0.03 * 255.0) ** 2
+    n = win * win
+    tot, cnt = 0.0, 0
+    for i in range(h - win + 1):
+        for j in range(w - win + 1):
+            a = target[i:i + win, j:j + win].astype(np.int64).ravel()
+            b = pred[i:i + win, j:j + win].astype(np.int64).ravel()
+            ma, mb = a.sum() / n, b.sum() / n
+            va = ((a * a).sum() - a.sum() ** 2 / n) / (n - 1)
+            vb = ((b * b).sum() - b.sum() ** 2 / n) / (n - 1)
+            vab = ((a * b).sum() - a.sum() * b.sum() / n) / (n - 1)
+            tot += ((2 * ma * mb + c1) * (2 * vab + c2)) / ((ma * ma + mb * mb + c1) * (va + vb + c2))
+            cnt += 1
+    return tot / cnt
