@@ -140,6 +140,9 @@ class Context:
         if n == 0:
             if h < 16 or w < 16:
                 raise RuntimeError(f"input {h}x{w} is too small for four 2x2 max-pools (need >= 16)")
+            if h * w >= 1 << 26:
+                raise RuntimeError(f"input {h}x{w} has 2^26 pixels or more: cut it into row bands "
+                                   "(tiling.forward_tiled / forward_strip)")
             check(1, "fiunet_workspace_bytes")
         return n
 

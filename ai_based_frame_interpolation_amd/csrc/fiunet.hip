@@ -100,6 +100,9 @@ struct Plan {
 bool make_plan(int B, int H, int W, int precision, Plan& p)
 {
     if (B < 1 || H < 16 || W < 16) return false;
+    // the kernels address a pixel record inside one image plane with 32 bits: H*W*64 B < 4 GiB.
+    // Larger frames go through fiunet_forward_strip band by band.
+    if ((long long)H * W >= (1LL << 26)) return false;
     const size_t es = precision == FIUNET_BF16 ? 2 : 4;
     p.hs[0] = H; p.ws[0] = W;
     for (int k = 1; k < 5; ++k) { p.hs[k] = p.hs[k - 1] / 2; p.ws[k] = p.ws[k - 1] / 2; }
@@ -605,7 +608,9 @@ int fiunet_forward_strip(fiunet_ctx* ctx, const float* frame1, const float* fram
     if (H < 16 || W < 16)
         return fail(FIUNET_ERR_BAD_SHAPE, "H and W must be >= 16 (four 2x2 max-pools)");
     Plan p;
-    make_plan(B, H, W, precision, p);
+    if (!make_plan(B, H, W, precision, p))
+        return fail(FIUNET_ERR_BAD_SHAPE, "H*W must be below 2^26 pixels per call: cut taller frames into "
+                                          "bands (fiunet_forward_strip)");
     if (workspace_bytes < p.total) return fail(FIUNET_ERR_WORKSPACE, "workspace too small");
     if ((uintptr_t)workspace & 255) return fail(FIUNET_ERR_INVALID_ARG, "workspace not 256-B aligned");
     HIP_TRY(hipSetDevice(ctx->device));

@@ -95,3 +95,11 @@ def test_strip_argument_errors(model, dev):
         model.forward_strip(x, x, 224, 256)  # runs past the image
     out = model.forward_strip(x[..., :40, :].contiguous(), x[..., :40, :].contiguous(), 16, 56)  # ends the image
     assert out.shape == (1, 1, 40, 32)
+
+
+def test_oversized_frame_is_refused_and_tiles_instead(model, dev):
+    """H*W >= 2^26 pixels would overflow the kernels' 32-bit in-plane offsets: refused loudly."""
+    model.precision = "bf16"
+    x = torch.zeros(1, 1, 8192, 8192, device=dev)
+    with pytest.raises(RuntimeError, match="row bands"):
+        model(x, x)
