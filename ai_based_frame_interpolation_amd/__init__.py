@@ -6,11 +6,11 @@ from .inference import (  # noqa: F401
     FrameInterpolator, generate_multiple_intermediate_frames, interpolate_frames,
     interpolate_sequence, interpolate_sequence_host, load_model, postprocess_image, preprocess_image,
 )
-from . import metrics, tiling, video  # noqa: F401
+from . import evaluation, metrics, tiling, video  # noqa: F401
 
 __all__ = [
     "FrameInterpolationUNet", "GraphedForward", "UNet", "count_parameters", "FrameInterpolator",
     "generate_multiple_intermediate_frames", "interpolate_frames", "interpolate_sequence",
     "interpolate_sequence_host",
-    "load_model", "postprocess_image", "preprocess_image", "metrics", "tiling", "video",
+    "load_model", "postprocess_image", "preprocess_image", "evaluation", "metrics", "tiling", "video",
 ]
