@@ -679,7 +679,8 @@ int fiunet_psnr_u8(const uint8_t* pred, const uint8_t* target, int images, int H
     unsigned long long* sums = (unsigned long long*)workspace;
     const size_t n = (size_t)H * W;
     HIP_TRY(hipMemsetAsync(sums, 0, (size_t)images * 8, s));
-    const unsigned bx = (unsigned)std::min<size_t>((n / 16 + 255) / 256 + 1, 1024);
+    // ~4 x 16 B per thread and at most 128 workgroups (= atomics) per image
+    const unsigned bx = (unsigned)std::min<size_t>((n / 64 + 255) / 256 + 1, 128);
     hipLaunchKernelGGL(sqdiff_u8_kernel, dim3(bx, (unsigned)images), dim3(256), 0, s, pred, target, n, sums);
     HIP_TRY(hipGetLastError());
     hipLaunchKernelGGL(psnr_finalize_kernel, dim3((images + 63) / 64), dim3(64), 0, s, sums, n, out, images);

@@ -52,7 +52,14 @@ __global__ __launch_bounds__(256) void sqdiff_u8_kernel(const uint8_t* __restric
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
-    if ((threadIdx.x & 63) == 0 && s) atomicAdd(sums + img, s);
+    // one atomic per workgroup (the 8 per-image counters are a serialisation point in L2)
+    __shared__ unsigned long long part[4];
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const unsigned long long t = part[0] + part[1] + part[2] + part[3];
+        if (t) atomicAdd(sums + img, t);
+    }
 }
 
 __global__ void psnr_finalize_kernel(const unsigned long long* __restrict__ sums, size_t n,
