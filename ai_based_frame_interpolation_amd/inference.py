@@ -186,6 +186,7 @@ def interpolate_sequence_host(model, frames_u8_cpu: torch.Tensor, batch: int = 8
         s, cnt = chunks[i]
         with torch.cuda.stream(copy):
             copy.wait_event(comp_done[i])
+            dmid[i].record_stream(copy)  # allocated on the compute stream, read by the copy stream
             for j in range(cnt):  # one contiguous 2-MB copy per frame (a strided view would be staged)
                 out[2 * (s + j) + 1].copy_(dmid[i][j, 0], non_blocking=True)
         dbuf.pop(i, None)
