@@ -402,6 +402,171 @@ template <int BN, int TH, int TW, int MODE> struct ConvTile {
 constexpr int conv_wave_frags(int BN, int TH, int TW) { return TH * TW / 16 / (4 / (BN / 64)); }
 constexpr int conv_occupancy(int BN, int TH, int TW) { return conv_wave_frags(BN, TH, TW) == 4 ? 3 : 2; }
 
+// ---- epilogue shared by the conv kernels: y = relu(acc * scale + shift) -> blocked activation
+//      records (+ fused pool / head / split-K slab).  acc[m][n]: accumulator tile m (16 couts) x
+//      pixel fragment n of the wave (wc = cout half, wp = pixel group) of workgroup tile (b, y0, x0),
+//      cout tile ct, K slice `split`.
+template <typename T, int BN, int TH, int TW, int EPI>
+__device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x4 (&acc)[4][conv_wave_frags(BN, TH, TW)],
+                                              int b, int y0, int x0, int ct, int split, int wc, int wp,
+                                              int l15, int lc)
+{
+    constexpr int PL = Elem<T>::PL;
+    constexpr int FR = TW / 16;
+    constexpr int NF = conv_wave_frags(BN, TH, TW);
+    constexpr int ROWS_W = NF / FR;
+    constexpr int HNC = EPI == EPI_HEAD ? 1 : (EPI == EPI_HEAD3 ? 3 : 0);
+    const int aH = a.H, aW = a.W;
+    // ---- epilogue: y = relu(acc * scale + shift) -> blocked activation records -------------------
+    // Which couts a lane holds: accumulator tile m, register j of lane group lc is MFMA row
+    // lc*4+j of that tile.  fp32: row r of tile m <-> cout m*16+r, so a lane's 4 registers are one
+    // 16-B quarter of the tile's 64-B plane record.  bf16: the packed weight rows are permuted on
+    // the host (fiunet.hip, `bf16_row_to_cout`) so that tiles 2g and 2g+1 together give the lane
+    // the 8 consecutive couts g*32+lc*8 .. +7: ONE 16-B store per lane and tile pair, and the 4
+    // lane groups of a pixel write its whole 64-B record (1 KiB contiguous per store instruction).
+    constexpr bool PERM = sizeof(T) == 2;
+    const int wbase_c = ct * BN + wc * 64;  // first cout of this wave
+    auto cofs = [&](int m) __attribute__((always_inline)) {  // cout (within the wave) of register j=0
+        return PERM ? (m >> 1) * 32 + lc * 8 + (m & 1) * 4 : m * 16 + lc * 4;
+    };
+    if constexpr (EPI == EPI_SPLITK) {
+        float* const slab = a.kslab + (size_t)split * a.B * aH * aW * a.Cout;
+#pragma unroll
+        for (int n = 0; n < NF; ++n) {
+            const int y = y0 + wp * ROWS_W + n / FR;
+            const int x = x0 + (n % FR) * 16 + l15;
+            if (y < aH && x < aW) {
+                float* o = slab + (((size_t)b * aH + y) * aW + x) * a.Cout + wbase_c;
+#pragma unroll
+                for (int m = 0; m < 4; ++m)
+                    *reinterpret_cast<float4*>(o + cofs(m)) =
+                        make_float4(acc[m][n][0], acc[m][n][1], acc[m][n][2], acc[m][n][3]);
+            }
+        }
+        return;
+    }
+    float4 sc[4], sh[4];
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+        sc[m] = *reinterpret_cast<const float4*>(a.scale + wbase_c + cofs(m));
+        sh[m] = *reinterpret_cast<const float4*>(a.shift + wbase_c + cofs(m));
+    }
+    float hw[HNC > 0 ? HNC : 1][4][4];
+#pragma unroll
+    for (int c = 0; c < HNC; ++c)
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+            const float4 v = *reinterpret_cast<const float4*>(a.head_w + c * 64 + cofs(m));
+            hw[c][m][0] = v.x; hw[c][m][1] = v.y; hw[c][m][2] = v.z; hw[c][m][3] = v.w;
+        }
+    // record address = image base + plane * plane_stride + pixel * 64 + byte within the record
+    const size_t plane_stride = (size_t)aH * aW * 64;
+    const int plane0 = wbase_c / PL;                       // first output plane of this wave
+    const int rec_byte = PERM ? lc * 16 : lc * 16;         // this lane's 16 B of a 64-B record
+    char* const out_img = a.dst ? (char*)a.dst + (size_t)b * plane_stride * (a.Cout / PL) +
+                                  (size_t)plane0 * plane_stride + rec_byte : nullptr;
+    const int pH = aH >> 1, pW = aW >> 1;  // EPI_POOL: MaxPool2d(2) output size (floor)
+    const size_t pplane_stride = (size_t)pH * pW * 64;
+    char* const pool_img = EPI == EPI_POOL ? (char*)a.pool_dst + (size_t)b * pplane_stride * (a.Cout / PL) +
+                                             (size_t)plane0 * pplane_stride + rec_byte : nullptr;
+#pragma unroll
+    for (int n = 0; n < NF; ++n) {
+        const int y = y0 + wp * ROWS_W + n / FR;
+        const int x = x0 + (n % FR) * 16 + l15;
+        const bool ok = (y < aH) && (x < aW);
+        float hsum[HNC > 0 ? HNC : 1] = {};
+        float v[4][4];
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+            v[m][0] = fmaf(acc[m][n][0], sc[m].x, sh[m].x);
+            v[m][1] = fmaf(acc[m][n][1], sc[m].y, sh[m].y);
+            v[m][2] = fmaf(acc[m][n][2], sc[m].z, sh[m].z);
+            v[m][3] = fmaf(acc[m][n][3], sc[m].w, sh[m].w);
+            if (a.relu) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) v[m][j] = fmaxf(v[m][j], 0.f);
+            }
+#pragma unroll
+            for (int c = 0; c < HNC; ++c)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) hsum[c] = fmaf(v[m][j], hw[c][m][j], hsum[c]);
+            if (EPI == EPI_POOL) {
+                // keep the post-activation values in acc: the 2x2 max below needs the row pair
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[m][n][j] = v[m][j];
+            }
+        }
+        if (ok && out_img) {
+            char* o = out_img + (size_t)(y * aW + x) * 64;
+            if constexpr (PERM) {
+#pragma unroll
+                for (int g = 0; g < 2; ++g)
+                    *reinterpret_cast<uint4*>(o + g * plane_stride) = make_uint4(
+                        pack_bf16x2(v[2 * g][0], v[2 * g][1]), pack_bf16x2(v[2 * g][2], v[2 * g][3]),
+                        pack_bf16x2(v[2 * g + 1][0], v[2 * g + 1][1]),
+                        pack_bf16x2(v[2 * g + 1][2], v[2 * g + 1][3]));
+            } else {
+#pragma unroll
+                for (int m = 0; m < 4; ++m)
+                    *reinterpret_cast<float4*>(o + m * plane_stride) =
+                        make_float4(v[m][0], v[m][1], v[m][2], v[m][3]);
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < HNC; ++c) {
+            float s = hsum[c];
+            s += __shfl_xor(s, 16);
+            s += __shfl_xor(s, 32);
+            if (ok && lc == 0)
+                a.head_out[(((size_t)b * HNC + c) * aH + y) * aW + x] = s + a.head_b[c];
+        }
+    }
+    if (EPI == EPI_POOL) {
+        // MaxPool2d(2) of this conv's output (unet.py:28), fused here so the consumer conv reads a
+        // ready tensor by LDS-DMA: tile origins are even, a wave owns whole row pairs (fragments n
+        // and n+FR) and the column partner is the neighbouring lane (l15 ^ 1).
+        // max(round(a), round(b)) == round(max(a, b)), so this equals pooling the stored tensor.
+#pragma unroll
+        for (int n = 0; n < NF; ++n) {
+            if (((n / FR) & 1) != 0) continue;  // upper row of each pair only
+            const int y = y0 + wp * ROWS_W + n / FR;
+            const int x = x0 + (n % FR) * 16 + l15;
+            const int py = y >> 1, px = x >> 1;
+            const bool okp = (py < pH) && (px < pW) && ((l15 & 1) == 0);
+            char* o = pool_img + (size_t)(min(py, pH - 1) * pW + min(px, pW - 1)) * 64;
+            if constexpr (!PERM) {
+#pragma unroll
+                for (int m = 0; m < 4; ++m) {
+                    float r[4];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const float cm = fmaxf(acc[m][n][j], acc[m][n + FR][j]);
+                        r[j] = fmaxf(cm, __uint_as_float(dpp_swap_pairs(__float_as_uint(cm))));
+                    }
+                    if (okp) *reinterpret_cast<float4*>(o + m * pplane_stride) = make_float4(r[0], r[1], r[2], r[3]);
+                }
+            } else {
+                // values are >= 0 (post-ReLU): packed int16 max on the rounded bf16 pairs
+#pragma unroll
+                for (int g = 0; g < 2; ++g) {
+                    unsigned r[4];
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) {
+                        const int m = 2 * g + h;
+                        const unsigned a0 = pk_max_i16(pack_bf16x2(acc[m][n][0], acc[m][n][1]),
+                                                       pack_bf16x2(acc[m][n + FR][0], acc[m][n + FR][1]));
+                        const unsigned a1 = pk_max_i16(pack_bf16x2(acc[m][n][2], acc[m][n][3]),
+                                                       pack_bf16x2(acc[m][n + FR][2], acc[m][n + FR][3]));
+                        r[2 * h] = pk_max_i16(a0, dpp_swap_pairs(a0));
+                        r[2 * h + 1] = pk_max_i16(a1, dpp_swap_pairs(a1));
+                    }
+                    if (okp) *reinterpret_cast<uint4*>(o + g * pplane_stride) = make_uint4(r[0], r[1], r[2], r[3]);
+                }
+            }
+        }
+    }
+}
+
 template <typename T, int BN, int TH, int TW, int MODE, int EPI>
 __global__ __launch_bounds__(256, conv_occupancy(BN, TH, TW)) void conv3x3_mfma_kernel(const ConvArgs a)
 {
@@ -800,154 +965,7 @@ __global__ __launch_bounds__(256, conv_occupancy(BN, TH, TW)) void conv3x3_mfma_
         }
     }
 
-    // ---- epilogue: y = relu(acc * scale + shift) -> blocked activation records -------------------
-    // Which couts a lane holds: accumulator tile m, register j of lane group lc is MFMA row
-    // lc*4+j of that tile.  fp32: row r of tile m <-> cout m*16+r, so a lane's 4 registers are one
-    // 16-B quarter of the tile's 64-B plane record.  bf16: the packed weight rows are permuted on
-    // the host (fiunet.hip, `bf16_row_to_cout`) so that tiles 2g and 2g+1 together give the lane
-    // the 8 consecutive couts g*32+lc*8 .. +7: ONE 16-B store per lane and tile pair, and the 4
-    // lane groups of a pixel write its whole 64-B record (1 KiB contiguous per store instruction).
-    constexpr bool PERM = sizeof(T) == 2;
-    const int wbase_c = ct * BN + wc * 64;  // first cout of this wave
-    auto cofs = [&](int m) __attribute__((always_inline)) {  // cout (within the wave) of register j=0
-        return PERM ? (m >> 1) * 32 + lc * 8 + (m & 1) * 4 : m * 16 + lc * 4;
-    };
-    if constexpr (EPI == EPI_SPLITK) {
-        float* const slab = a.kslab + (size_t)split * a.B * aH * aW * a.Cout;
-#pragma unroll
-        for (int n = 0; n < NF; ++n) {
-            const int y = y0 + wp * ROWS_W + n / FR;
-            const int x = x0 + (n % FR) * 16 + l15;
-            if (y < aH && x < aW) {
-                float* o = slab + (((size_t)b * aH + y) * aW + x) * a.Cout + wbase_c;
-#pragma unroll
-                for (int m = 0; m < 4; ++m)
-                    *reinterpret_cast<float4*>(o + cofs(m)) =
-                        make_float4(acc[m][n][0], acc[m][n][1], acc[m][n][2], acc[m][n][3]);
-            }
-        }
-        return;
-    }
-    float4 sc[4], sh[4];
-#pragma unroll
-    for (int m = 0; m < 4; ++m) {
-        sc[m] = *reinterpret_cast<const float4*>(a.scale + wbase_c + cofs(m));
-        sh[m] = *reinterpret_cast<const float4*>(a.shift + wbase_c + cofs(m));
-    }
-    float hw[HNC > 0 ? HNC : 1][4][4];
-#pragma unroll
-    for (int c = 0; c < HNC; ++c)
-#pragma unroll
-        for (int m = 0; m < 4; ++m) {
-            const float4 v = *reinterpret_cast<const float4*>(a.head_w + c * 64 + cofs(m));
-            hw[c][m][0] = v.x; hw[c][m][1] = v.y; hw[c][m][2] = v.z; hw[c][m][3] = v.w;
-        }
-    // record address = image base + plane * plane_stride + pixel * 64 + byte within the record
-    const size_t plane_stride = (size_t)aH * aW * 64;
-    const int plane0 = wbase_c / PL;                       // first output plane of this wave
-    const int rec_byte = PERM ? lc * 16 : lc * 16;         // this lane's 16 B of a 64-B record
-    char* const out_img = a.dst ? (char*)a.dst + (size_t)b * plane_stride * (a.Cout / PL) +
-                                  (size_t)plane0 * plane_stride + rec_byte : nullptr;
-    const int pH = aH >> 1, pW = aW >> 1;  // EPI_POOL: MaxPool2d(2) output size (floor)
-    const size_t pplane_stride = (size_t)pH * pW * 64;
-    char* const pool_img = EPI == EPI_POOL ? (char*)a.pool_dst + (size_t)b * pplane_stride * (a.Cout / PL) +
-                                             (size_t)plane0 * pplane_stride + rec_byte : nullptr;
-#pragma unroll
-    for (int n = 0; n < NF; ++n) {
-        const int y = y0 + wp * ROWS_W + n / FR;
-        const int x = x0 + (n % FR) * 16 + l15;
-        const bool ok = (y < aH) && (x < aW);
-        float hsum[HNC > 0 ? HNC : 1] = {};
-        float v[4][4];
-#pragma unroll
-        for (int m = 0; m < 4; ++m) {
-            v[m][0] = fmaf(acc[m][n][0], sc[m].x, sh[m].x);
-            v[m][1] = fmaf(acc[m][n][1], sc[m].y, sh[m].y);
-            v[m][2] = fmaf(acc[m][n][2], sc[m].z, sh[m].z);
-            v[m][3] = fmaf(acc[m][n][3], sc[m].w, sh[m].w);
-            if (a.relu) {
-#pragma unroll
-                for (int j = 0; j < 4; ++j) v[m][j] = fmaxf(v[m][j], 0.f);
-            }
-#pragma unroll
-            for (int c = 0; c < HNC; ++c)
-#pragma unroll
-                for (int j = 0; j < 4; ++j) hsum[c] = fmaf(v[m][j], hw[c][m][j], hsum[c]);
-            if (EPI == EPI_POOL) {
-                // keep the post-activation values in acc: the 2x2 max below needs the row pair
-#pragma unroll
-                for (int j = 0; j < 4; ++j) acc[m][n][j] = v[m][j];
-            }
-        }
-        if (ok && out_img) {
-            char* o = out_img + (size_t)(y * aW + x) * 64;
-            if constexpr (PERM) {
-#pragma unroll
-                for (int g = 0; g < 2; ++g)
-                    *reinterpret_cast<uint4*>(o + g * plane_stride) = make_uint4(
-                        pack_bf16x2(v[2 * g][0], v[2 * g][1]), pack_bf16x2(v[2 * g][2], v[2 * g][3]),
-                        pack_bf16x2(v[2 * g + 1][0], v[2 * g + 1][1]),
-                        pack_bf16x2(v[2 * g + 1][2], v[2 * g + 1][3]));
-            } else {
-#pragma unroll
-                for (int m = 0; m < 4; ++m)
-                    *reinterpret_cast<float4*>(o + m * plane_stride) =
-                        make_float4(v[m][0], v[m][1], v[m][2], v[m][3]);
-            }
-        }
-#pragma unroll
-        for (int c = 0; c < HNC; ++c) {
-            float s = hsum[c];
-            s += __shfl_xor(s, 16);
-            s += __shfl_xor(s, 32);
-            if (ok && lc == 0)
-                a.head_out[(((size_t)b * HNC + c) * aH + y) * aW + x] = s + a.head_b[c];
-        }
-    }
-    if (EPI == EPI_POOL) {
-        // MaxPool2d(2) of this conv's output (unet.py:28), fused here so the consumer conv reads a
-        // ready tensor by LDS-DMA: tile origins are even, a wave owns whole row pairs (fragments n
-        // and n+FR) and the column partner is the neighbouring lane (l15 ^ 1).
-        // max(round(a), round(b)) == round(max(a, b)), so this equals pooling the stored tensor.
-#pragma unroll
-        for (int n = 0; n < NF; ++n) {
-            if (((n / FR) & 1) != 0) continue;  // upper row of each pair only
-            const int y = y0 + wp * ROWS_W + n / FR;
-            const int x = x0 + (n % FR) * 16 + l15;
-            const int py = y >> 1, px = x >> 1;
-            const bool okp = (py < pH) && (px < pW) && ((l15 & 1) == 0);
-            char* o = pool_img + (size_t)(min(py, pH - 1) * pW + min(px, pW - 1)) * 64;
-            if constexpr (!PERM) {
-#pragma unroll
-                for (int m = 0; m < 4; ++m) {
-                    float r[4];
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        const float cm = fmaxf(acc[m][n][j], acc[m][n + FR][j]);
-                        r[j] = fmaxf(cm, __uint_as_float(dpp_swap_pairs(__float_as_uint(cm))));
-                    }
-                    if (okp) *reinterpret_cast<float4*>(o + m * pplane_stride) = make_float4(r[0], r[1], r[2], r[3]);
-                }
-            } else {
-                // values are >= 0 (post-ReLU): packed int16 max on the rounded bf16 pairs
-#pragma unroll
-                for (int g = 0; g < 2; ++g) {
-                    unsigned r[4];
-#pragma unroll
-                    for (int h = 0; h < 2; ++h) {
-                        const int m = 2 * g + h;
-                        const unsigned a0 = pk_max_i16(pack_bf16x2(acc[m][n][0], acc[m][n][1]),
-                                                       pack_bf16x2(acc[m][n + FR][0], acc[m][n + FR][1]));
-                        const unsigned a1 = pk_max_i16(pack_bf16x2(acc[m][n][2], acc[m][n][3]),
-                                                       pack_bf16x2(acc[m][n + FR][2], acc[m][n + FR][3]));
-                        r[2 * h] = pk_max_i16(a0, dpp_swap_pairs(a0));
-                        r[2 * h + 1] = pk_max_i16(a1, dpp_swap_pairs(a1));
-                    }
-                    if (okp) *reinterpret_cast<uint4*>(o + g * pplane_stride) = make_uint4(r[0], r[1], r[2], r[3]);
-                }
-            }
-        }
-    }
+    conv_epilogue<T, BN, TH, TW, EPI>(a, acc, b, y0, x0, ct, split, wc, wp, l15, lc);
 #ifdef FIUNET_STAMP
     STAMP(5);
     st_sum[0] = st_prev - st_t0;
@@ -960,5 +978,6 @@ __global__ __launch_bounds__(256, conv_occupancy(BN, TH, TW)) void conv3x3_mfma_
     }
 #endif
 }
+
 
 }  // namespace fiunet
