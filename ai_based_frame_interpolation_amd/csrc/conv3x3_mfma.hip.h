@@ -646,15 +646,8 @@ __global__ __launch_bounds__(256, conv_occupancy(BN, TH, TW)) void conv3x3_mfma_
         const int kx = lrow / BN, row = lrow - kx * BN;
         w_src_off[j] = (kx * a.Cout + row) * 64 + (((lane & 3) ^ swz(lrow)) << 4);
     }
-    // position q in the K loop -> plane.  (experiment FIUNET_INTERLEAVE: alternate skip / upsampled planes)
-    auto pmap = [&](int q) __attribute__((always_inline)) {
-#ifdef FIUNET_INTERLEAVE
-        if (MODE == SRC_CONCAT_UP && 2 * p0 == nplanes_all) return (q & 1) ? p0 + (q >> 1) : (q >> 1);
-#endif
-        return q;
-    };
     auto issue_w = [&](int step) __attribute__((always_inline)) {  // step counts from this slice's start
-        const int lp = step / 3, ky = step - lp * 3, pl = pmap(pbeg + lp);
+        const int lp = step / 3, ky = step - lp * 3, pl = pbeg + lp;
         const char* wsrc = wbase + ((size_t)(pl * 9 + ky * 3) * a.Cout) * 64;
         const unsigned dst = __builtin_amdgcn_readfirstlane(
             lds_w_addr + (unsigned)((step & 1) * Tile::W_STRIDE + wave * NW * 1024));
@@ -921,7 +914,7 @@ __global__ __launch_bounds__(256, conv_occupancy(BN, TH, TW)) void conv3x3_mfma_
         stage_patch();
         __syncthreads();
     }
-    gather_plane(pmap(pbeg), 1);
+    gather_plane(pbeg, 1);
     lds_dma_wait_all();
     __syncthreads();
     STAMP(1);
@@ -960,7 +953,7 @@ __global__ __launch_bounds__(256, conv_occupancy(BN, TH, TW)) void conv3x3_mfma_
             STAMP(2);
             if (ky == 2 && plane + 1 < pend) {
                 __syncthreads();  // every wave is done with this plane's in-tile and with W(step)
-                gather_plane(pmap(plane + 1), step & 1);
+                gather_plane(plane + 1, step & 1);
                 lds_dma_wait_all();
                 __syncthreads();
                 STAMP(4);
