@@ -8,22 +8,35 @@
 A step = one forward of the hot path over one batch of synthetic frame pairs that is already
 resident in HBM.  Default workload = BASELINE.json configs[2]: batch 8 of 1920x1080 pairs, bf16
 MFMA path, one batch per GPU (weak scaling: frame pairs are independent, ranks exchange
-nothing inside the timed region).  Rank 0 prints ONE JSON line.
+nothing inside the timed region).  Rank 0 prints ONE JSON line; `value` is always this leg.
 
 Extra objects on that line:
-  roofline     -- dominant kernel (by time) of the forward: algorithmic FLOPs per launch / its
-                  average launch duration, measured live with HIP events recorded on the launch
-                  stream between the stages (fiunet_profile_*), vs the dense MFMA peak.
-  cpu_baseline -- the PyTorch-CPU oracle (a port of the reference's forward, pinned to reference
-                  outputs) timed on this box's host cores on ONE 1080p pair (N=1, rank 0 only).
+  roofline      -- dominant kernel (by time) of the forward: algorithmic FLOPs per launch / its
+                   average launch duration, measured live with HIP events recorded on the launch
+                   stream between the stages (fiunet_profile_*), vs the dense MFMA peak.
+  cpu_baseline  -- the PyTorch-CPU oracle (a port of the reference's forward, pinned to reference
+                   outputs) timed on this box's host cores: 1080p (1 warm-up + median of 3) and
+                   BASELINE configs[0] (one 256x256 pair, 3 warm-up + 10 timed, median), thread
+                   count chosen by a short sweep; N=1, rank 0 only.
+  parity        -- PSNR of the HIP path and of the CPU oracle against a TRUE middle frame on a
+                   checkpoint that interpolates (north_star: within 0.05 dB), and the raw bf16 error
+                   of the bench's own random network.
+  video_sharded -- BASELINE configs[3]: a synthetic 1080p uint8 video held by rank 0, factor 2,
+                   end to end through video.interpolate_video_sharded (RCCL send/recv scatter of
+                   frame sub-batches, forward_u8, gather), beside the replicas-only `value`.
+  tile4k        -- BASELINE configs[4] (N >= 2): one 2160x3840 pair cut into N row bands + halo
+                   through tiling.forward_tiled_distributed.
 The oracle is only the baseline/checker here; the measured path never touches it.
 """
 from __future__ import annotations
 
 import argparse
+import datetime
 import json
 import os
+import statistics
 import sys
+import threading
 import time
 
 import torch
@@ -33,6 +46,7 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 import ai_based_frame_interpolation_amd as P  # noqa: E402
+from ai_based_frame_interpolation_amd import synthetic as S  # noqa: E402
 
 PEAK_TFLOPS = {"bf16": 2500.0, "fp32": 157.3}   # MI355X dense MFMA peaks (MI355X_MICROARCH.md)
 PEAK_HBM_GBS = 8000.0
@@ -54,17 +68,29 @@ def conv_flops(h, w):
     return tot + 2.0 * h * w * 64
 
 
-def moving_pattern(t, h, w, device):
-    """Seeded procedural frame (moving blobs + fixed texture) in [0,255] uint8 -> gives the PSNR
-    leg a ground-truth middle frame: frames at t=0,2 in, t=1 is the truth."""
-    ys = torch.arange(h, device=device, dtype=torch.float32)[:, None]
-    xs = torch.arange(w, device=device, dtype=torch.float32)[None, :]
-    img = 96 + 40 * torch.sin(xs / 37.0 + 0.11 * t) * torch.cos(ys / 23.0)
-    for k in range(6):
-        cx = (0.13 * (k + 1) * w + 9.0 * t * (k + 1)) % w
-        cy = (0.29 * (k + 1) * h + 5.0 * t) % h
-        img = img + 90 * torch.exp(-((xs - cx) ** 2 + (ys - cy) ** 2) / (2 * (18.0 + 6 * k) ** 2))
-    return img.clamp(0, 255).to(torch.uint8)
+def make_bench_model(precision: str, seed: int = 0) -> "P.FrameInterpolationUNet":
+    """Random-init network of the benchmark: He-scaled conv weights and non-trivial BatchNorm
+    statistics so activations stay O(1) through all 19 layers (torch's default init + identity BN
+    decays towards zero, and near-zero MFMA operands run at a higher clock than real data: never
+    bench on those).  Same weights on every rank."""
+    torch.manual_seed(seed)
+    model = P.FrameInterpolationUNet(bilinear=True, precision=precision)
+    with torch.no_grad():
+        for name, prm in model.named_parameters():
+            if prm.dim() == 4 and prm.shape[-1] == 3:
+                prm.normal_(0, (2.0 / (prm.shape[1] * 9)) ** 0.5)
+            elif prm.dim() == 4:
+                prm.normal_(0, 0.2 / prm.shape[1] ** 0.5)
+            elif name.endswith(".weight"):
+                prm.uniform_(0.6, 1.6)
+            elif name.endswith(".bias"):
+                prm.normal_(0, 0.25 if "double_conv" in name else 0.1)
+        for name, buf in model.named_buffers():
+            if name.endswith("running_mean"):
+                buf.normal_(0, 0.2)
+            elif name.endswith("running_var"):
+                buf.uniform_(0.5, 1.5)
+    return model
 
 
 class _quiet_native_stdout:
@@ -82,6 +108,226 @@ class _quiet_native_stdout:
         os.close(self._saved)
 
 
+def _run_bounded(fn, seconds: float):
+    """Run `fn()` on a worker thread and give up after `seconds`: a leg that exercises RCCL
+    send/recv for the first time on a new node must not be able to take the headline number down
+    with it.  Returns (result, error string or None)."""
+    box = {}
+
+    def body():
+        try:
+            box["r"] = fn()
+        except Exception as e:  # noqa: BLE001 -- reported in the JSON, not swallowed
+            box["e"] = f"{type(e).__name__}: {e}"
+
+    t = threading.Thread(target=body, daemon=True)
+    t.start()
+    t.join(seconds)
+    if t.is_alive():
+        return None, f"timeout after {seconds:.0f} s"
+    return box.get("r"), box.get("e")
+
+
+# ---------------------------------------------------------------------------------------------
+# CPU legs (rank 0, N = 1): the oracle is the timed baseline and the checker, nothing else
+# ---------------------------------------------------------------------------------------------
+def _cpu_info():
+    model = "?"
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                model = line.split(":", 1)[1].strip()
+                break
+    except OSError:
+        pass
+    quota = None
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()
+        quota = None if q == "max" else round(int(q) / int(per), 1)
+    except (OSError, ValueError):
+        pass
+    return model, len(os.sched_getaffinity(0)), quota
+
+
+def cpu_legs(dev, precision):
+    from oracle import unet_oracle as O  # checker / baseline only
+
+    cpu_model, n_aff, quota = _cpu_info()
+    # ---- thread count: short sweep on the 256x256 case -----------------------------------
+    sd_i = O.make_interpolating_state_dict()
+    g1, g2 = O.make_frames(0, 1, 256, 256)  # SURVEY 8d config 1: seed 0
+    cands = sorted({t for t in (4, 8, 16, 32, 64, 128) if t <= max(n_aff, 4)})
+    sweep = {}
+    for t in cands:
+        torch.set_num_threads(t)
+        O.unet_forward(sd_i, g1, g2)
+        ts = []
+        for _ in range(3):
+            t0 = time.perf_counter(); O.unet_forward(sd_i, g1, g2); ts.append(time.perf_counter() - t0)
+        sweep[t] = min(ts)
+    best = min(sweep, key=sweep.get)
+    torch.set_num_threads(best)
+    # ---- BASELINE configs[0]: one 256x256 pair, 3 warm-up + 10 timed, median -------------
+    for _ in range(3):
+        O.unet_forward(sd_i, g1, g2)
+    ts = []
+    for _ in range(10):
+        t0 = time.perf_counter(); O.unet_forward(sd_i, g1, g2); ts.append(time.perf_counter() - t0)
+    cfg1_ms = statistics.median(ts) * 1e3
+    # the HIP path on the same pair (latency, one pair per call, fp32 and bf16)
+    m = P.FrameInterpolationUNet(bilinear=True)
+    m.load_state_dict(sd_i)
+    m = m.to(dev).eval()
+    hip_cfg1 = {}
+    for prec in ("fp32", "bf16"):
+        m.precision = prec
+        d1, d2 = g1.to(dev), g2.to(dev)
+        for _ in range(5):
+            m(d1, d2)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(50):
+            m(d1, d2)
+        torch.cuda.synchronize()
+        hip_cfg1[prec] = round((time.perf_counter() - t0) / 50 * 1e3, 3)
+    # ---- 1080p: 1 warm-up + 3 timed, median; inputs/outputs stay on the host -------------
+    h, w = 1080, 1920
+    a_u8, truth_u8, c_u8 = S.triplet(h, w, device="cpu", seed=3)
+    fa, fc = O.preprocess_array(a_u8.numpy()), O.preprocess_array(c_u8.numpy())
+    ref = O.unet_forward(sd_i, fa, fc)
+    ts = []
+    for _ in range(3):
+        t0 = time.perf_counter(); ref = O.unet_forward(sd_i, fa, fc); ts.append(time.perf_counter() - t0)
+    cpu_s = statistics.median(ts)
+    cpu_baseline = {
+        "value": round(1.0 / cpu_s, 4), "unit": "frames/s", "cores": best, "kind": "port",
+        "sample": f"one 1920x1080 frame pair, 1 warm-up + median of 3 runs ({', '.join(f'{t:.2f}' for t in ts)} s), "
+                  f"PyTorch-CPU oracle (oracle/unet_oracle.py), fp32, torch {torch.__version__}, "
+                  f"{best} threads chosen by a sweep over {cands} on the 256x256 case; CPU: {cpu_model}, "
+                  f"{n_aff} logical CPUs visible" + (f", cgroup quota {quota} CPUs" if quota else ""),
+        "config1_256x256": {"cpu_ms_median": round(cfg1_ms, 2), "cpu_frames_per_s": round(1e3 / cfg1_ms, 2),
+                            "protocol": "1 pair, 3 warm-up + 10 timed, median (SURVEY 8d config 1)",
+                            "hip_ms_fp32": hip_cfg1["fp32"], "hip_ms_bf16": hip_cfg1["bf16"]},
+        "thread_sweep_256x256_ms": {str(k): round(v * 1e3, 1) for k, v in sweep.items()},
+    }
+    # ---- PSNR vs a true middle frame, interpolating checkpoint, 1080p --------------------
+    ref_u8 = O.postprocess_tensor(ref)
+    par = {"checkpoint": "oracle.make_interpolating_state_dict(): 0.5*(f1+f2) carried through the x1 skip "
+                         "+ seeded random deep network (~0.04 rms)",
+           "psnr_cpu_vs_truth_db": round(O.psnr_u8(truth_u8.numpy(), ref_u8), 4)}
+    for prec in ("fp32", "bf16"):
+        m.precision = prec
+        hip_u8 = m.forward_u8(a_u8[None, None].to(dev), c_u8[None, None].to(dev))[0, 0].cpu().numpy()
+        par[f"psnr_hip_{prec}_vs_truth_db"] = round(O.psnr_u8(truth_u8.numpy(), hip_u8), 4)
+        par[f"psnr_hip_{prec}_vs_cpu_ref_u8_db"] = round(O.psnr_u8(ref_u8, hip_u8), 3)
+        out = m(fa.to(dev), fc.to(dev)).cpu()
+        par[f"max_abs_{prec}_vs_cpu_ref"] = round(float((out - ref).abs().max()), 8)
+    par["psnr_delta_db"] = round(abs(par[f"psnr_hip_{precision}_vs_truth_db"] - par["psnr_cpu_vs_truth_db"]), 4)
+    # ---- raw bf16 error of the bench's own random network (bounded size: 540x960) --------
+    bm = make_bench_model(precision).to(dev).eval()
+    sd_b = {k: v.detach().cpu() for k, v in bm.state_dict().items()}
+    b1, b2 = O.make_frames(2, 1, 540, 960)
+    bref = O.unet_forward(sd_b, b1, b2)
+    bout = bm(b1.to(dev), b2.to(dev)).cpu()
+    par["bench_network_540x960"] = {
+        "rel_l2_vs_cpu_ref": round(float((bout - bref).norm() / bref.norm()), 6),
+        "max_abs_vs_cpu_ref": round(float((bout - bref).abs().max()), 6),
+        "out_absmax": round(float(bref.abs().max()), 4),
+        "psnr_u8_vs_cpu_ref_db": round(O.psnr_u8(O.postprocess_tensor(bref), O.postprocess_tensor(bout)), 3),
+    }
+    return cpu_baseline, par
+
+
+# ---------------------------------------------------------------------------------------------
+# multi-GPU legs
+# ---------------------------------------------------------------------------------------------
+def video_leg(model, dev, dist, rank, world, n_frames, batch, h, w):
+    """BASELINE configs[3]: rank 0 holds the uint8 frames in HBM; scatter -> forward_u8 -> gather."""
+    from ai_based_frame_interpolation_amd import video as V
+
+    class _Solo:  # the same code path without a process group (plain `python bench.py`)
+        @staticmethod
+        def run(frames, n, out=None):
+            return P.interpolate_sequence(model, frames, batch=batch)
+
+    torch.cuda.set_device(dev)  # legs run on a worker thread: the current device is per thread
+
+    def pair_fn(a, c):  # [b,H,W] uint8 planes -> [b,H,W] middles, pre/post-processing on device
+        return model.forward_u8(a.unsqueeze(1), c.unsqueeze(1)).squeeze(1)
+
+    frames = S.moving_frames(0, n_frames, h, w, device=dev, seed=11) if rank == 0 else None
+    out = torch.empty((2 * n_frames - 1, h, w), dtype=torch.uint8, device=dev) if rank == 0 else None
+    warm_n = min(n_frames, 2 * world * batch + 1)
+
+    def run(n, o):
+        if dist is None:
+            return _Solo.run(frames[:n], n)
+        return V.interpolate_video_sharded(pair_fn, frames[:n] if rank == 0 else None, n,
+                                           (h, w), dev, batch=batch, root=0, out=o)
+
+    def sync():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    run(warm_n, out[:2 * warm_n - 1] if rank == 0 else None)   # RCCL connections, workspaces
+    sync()
+    t0 = time.perf_counter()
+    res = run(n_frames, out)
+    sync()
+    dt = time.perf_counter() - t0
+    ok = None
+    if rank == 0:  # spot-check three pairs against the single-GPU uint8 forward
+        ok = True
+        for i in (0, (n_frames - 1) // 2, n_frames - 2):
+            mid = model.forward_u8(frames[i][None, None], frames[i + 1][None, None])[0, 0]
+            ok = ok and bool(torch.equal(res[2 * i + 1], mid)) and bool(torch.equal(res[2 * i], frames[i]))
+    return {"frames_in": n_frames, "frames_out": 2 * n_frames - 1, "seconds": round(dt, 4),
+            "interpolated_frames_per_s": round((n_frames - 1) / dt, 2), "ranks": world,
+            "backend": "rccl (torch.distributed nccl) send/recv" if dist is not None else "single process",
+            "sub_batch_pairs": batch, "spot_check_equal_to_single_gpu": ok,
+            "note": "end to end: frames resident in rank 0's HBM -> interleaved uint8 result in rank 0's HBM"}
+
+
+def tile4k_leg(model, dev, dist, rank, world, reps):
+    """BASELINE configs[4]: one 2160x3840 pair, `world` row bands + 112-row halo."""
+    from ai_based_frame_interpolation_amd import tiling as T
+
+    torch.cuda.set_device(dev)
+    h, w = 2160, 3840
+    shape = (1, 1, h, w)
+    f1 = f2 = None
+    if rank == 0:
+        gen = torch.Generator(device=dev).manual_seed(5)
+        f1 = torch.rand(shape, device=dev, generator=gen) * 2 - 1
+        f2 = torch.rand(shape, device=dev, generator=gen) * 2 - 1
+
+    def once():
+        return T.forward_tiled_distributed(model.forward_strip, f1, f2, shape, dev, root=0)
+
+    for _ in range(2):
+        out = once()
+    dist.barrier(); torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        out = once()
+    dist.barrier(); torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / reps
+    res = {"ms_per_pair": round(dt * 1e3, 3), "pairs_per_s": round(1.0 / dt, 2), "strips": world,
+           "halo_rows": T.HALO, "precision": model.precision}
+    if rank == 0:
+        whole = model(f1, f2)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            whole = model(f1, f2)
+        torch.cuda.synchronize()
+        res["untiled_one_gpu_ms"] = round((time.perf_counter() - t0) / reps * 1e3, 3)
+        res["tiled_equals_untiled_bitwise"] = bool(torch.equal(out, whole))
+        res["tiled_vs_untiled_max_abs"] = float((out - whole).abs().max())
+    return res
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -93,6 +339,9 @@ def main():
     ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--unfused", action="store_true", help="ablation: separate pool/upsample/head kernels")
+    ap.add_argument("--video-frames", type=int, default=-1,
+                    help="frames of the config-4 video leg (default 3000 = BASELINE configs[3]; 0 = skip)")
+    ap.add_argument("--no-tile4k", action="store_true")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -107,34 +356,15 @@ def main():
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         with _quiet_native_stdout():
             torch.cuda.set_device(local_rank)
-            dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local_rank}"))
+            dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local_rank}"),
+                                    timeout=datetime.timedelta(seconds=600))
             dist.barrier()  # creates the RCCL communicator (and prints its banner) here, not later
             torch.cuda.synchronize()
     torch.cuda.set_device(local_rank)
     dev = torch.device(f"cuda:{local_rank}")
 
     b, h, w = args.batch, args.height, args.width
-    torch.manual_seed(0)  # same random-init weights on every rank
-    model = P.FrameInterpolationUNet(bilinear=True, precision=args.precision)
-    with torch.no_grad():
-        # He-scaled conv weights and non-trivial BatchNorm statistics so activations stay O(1)
-        # through all 19 layers (torch's default init + identity BN decays towards zero, and
-        # near-zero MFMA operands run at a higher clock than real data: never bench on those).
-        for name, prm in model.named_parameters():
-            if prm.dim() == 4 and prm.shape[-1] == 3:
-                prm.normal_(0, (2.0 / (prm.shape[1] * 9)) ** 0.5)
-            elif prm.dim() == 4:
-                prm.normal_(0, 0.2 / prm.shape[1] ** 0.5)
-            elif name.endswith(".weight"):
-                prm.uniform_(0.6, 1.6)
-            elif name.endswith(".bias"):
-                prm.normal_(0, 0.25 if "double_conv" in name else 0.1)
-        for name, buf in model.named_buffers():
-            if name.endswith("running_mean"):
-                buf.normal_(0, 0.2)
-            elif name.endswith("running_var"):
-                buf.uniform_(0.5, 1.5)
-    model = model.to(dev).eval()
+    model = make_bench_model(args.precision).to(dev).eval()
     model.set_options(unfused=args.unfused)
 
     gen = torch.Generator(device=dev).manual_seed(1 + rank)
@@ -161,12 +391,52 @@ def main():
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+    del f1, f2
+
+    # ---- config 4 / config 5 legs (every rank takes part; bounded, failures are reported) ----
+    default_workload = (b, h, w, args.precision, args.unfused) == (8, 1080, 1920, "bf16", False)
+    n_video = args.video_frames if args.video_frames >= 0 else (3000 if default_workload else 0)
+    video_res = tile_res = None
+    if n_video >= 2:
+        with _quiet_native_stdout():
+            video_res, err = _run_bounded(
+                lambda: video_leg(model, dev, dist, rank, world, n_video, b, h, w), 240.0)
+        if err:
+            video_res = {"error": err, "frames_in": n_video, "ranks": world}
+            if "timeout" in err:  # a hung transfer: nothing after it can run on this communicator
+                if rank == 0:
+                    print(json.dumps(headline(args, world, elapsed, rows, nfw, default_workload,
+                                              video_res, None, None, None)))
+                    sys.stdout.flush()
+                os._exit(0)
+    if dist is not None and world >= 2 and default_workload and not args.no_tile4k:
+        with _quiet_native_stdout():
+            tile_res, err = _run_bounded(lambda: tile4k_leg(model, dev, dist, rank, world, 10), 120.0)
+        if err:
+            tile_res = {"error": err, "strips": world}
+            if "timeout" in err:
+                if rank == 0:
+                    print(json.dumps(headline(args, world, elapsed, rows, nfw, default_workload,
+                                              video_res, tile_res, None, None)))
+                    sys.stdout.flush()
+                os._exit(0)
 
     if rank != 0:
         if dist is not None:
             dist.destroy_process_group()
         return
 
+    cpu_baseline = parity = None
+    if world == 1 and not args.no_cpu_baseline:
+        cpu_baseline, parity = cpu_legs(dev, args.precision)
+    print(json.dumps(headline(args, world, elapsed, rows, nfw, default_workload, video_res, tile_res,
+                              cpu_baseline, parity)))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+def headline(args, world, elapsed, rows, nfw, default_workload, video_res, tile_res, cpu_baseline, parity):
+    b, h, w = args.batch, args.height, args.width
     fps = world * b * args.steps / elapsed
     ms_step = elapsed / args.steps * 1e3
     flops_frame = conv_flops(h, w)
@@ -180,18 +450,22 @@ def main():
     dom_name, dom = max(groups.items(), key=lambda kv: kv[1]["ms"])
     peak = PEAK_TFLOPS[args.precision]
     achieved = dom["flops"] / (dom["ms"] * 1e-3) / 1e12 if dom["ms"] > 0 else 0.0
-    traffic = None
+    traffic = traffic_source = None
     pmc = os.path.join(ROOT, "profiles", "pmc_summary.json")
-    default_workload = (b, h, w, args.precision, args.unfused) == (8, 1080, 1920, "bf16", False)
     if os.path.exists(pmc) and default_workload:  # the committed PMC pass is of this workload only
         try:
-            traffic = json.load(open(pmc)).get(dom_name, {}).get("hbm_bytes_per_launch")
+            js = json.load(open(pmc))
+            traffic = js.get(dom_name, {}).get("hbm_bytes_per_launch")
+            meta = js.get("_meta", {})
+            traffic_source = ("profiles/pmc_summary.json: separate rocprofv3 --pmc passes (FETCH_SIZE x2 "
+                              "corrected + WRITE_SIZE, tools/profile_all.sh) of this command at commit "
+                              f"{meta.get('commit', '?')} on {meta.get('date', '?')}; NOT measured by this run")
         except Exception:
             traffic = None
     sum_ms = sum(r[1] for r in rows)
     roofline = {
         "bound": "mfma", "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s",
-        "frac": round(achieved / peak, 4), "traffic": traffic,
+        "frac": round(achieved / peak, 4), "traffic": traffic, "traffic_source": traffic_source,
         "kernel": dom_name, "launches_per_step": dom["launches"],
         "avg_launch_ms": round(dom["ms"] / dom["launches"], 4),
         "algorithmic_flops_per_launch": dom["flops"] / dom["launches"],
@@ -206,7 +480,6 @@ def main():
         "stages": [{"kernel": n, "ms": round(ms, 4), "tflops": round(fl / (ms * 1e-3) / 1e12, 1) if ms > 0 else 0}
                    for n, ms, fl in rows],
     }
-
     result = {
         "metric": "interpolated frames/sec at 1080p" if (h, w) == (1080, 1920) else f"interpolated frames/sec at {h}x{w}",
         "value": round(fps, 2), "unit": "frames/s", "n_gpus": world, "steps": args.steps,
@@ -218,47 +491,15 @@ def main():
                    "parallelism": f"frame-pair shard x{world}, no data-path collective"},
         "roofline": roofline,
     }
-
-    # ---- CPU baseline + PSNR leg (N=1 only; bounded: one 1080p pair) --------------------------
-    if world == 1 and not args.no_cpu_baseline:
-        from oracle import unet_oracle as O  # checker / baseline only
-        sd = {k: v.detach().cpu() for k, v in model.state_dict().items()}
-        ncores = os.cpu_count() or 1
-        torch.set_num_threads(ncores)
-        a_u8 = moving_pattern(0, h, w, dev)
-        c_u8 = moving_pattern(2, h, w, dev)
-        gt_u8 = moving_pattern(1, h, w, dev).cpu().numpy()
-        pa = P._native.preprocess_u8(a_u8[None, None])
-        pc = P._native.preprocess_u8(c_u8[None, None])
-        t0 = time.perf_counter()
-        ref = O.unet_forward(sd, pa.cpu(), pc.cpu())
-        cpu_s = time.perf_counter() - t0
-        out = model(pa, pc)
-        ref_u8 = O.postprocess_tensor(ref)
-        hip_u8 = P.postprocess_image(out)
-        model.precision = "fp32"
-        out32 = model(pa, pc)
-        model.precision = args.precision
-        result["cpu_baseline"] = {
-            "value": round(1.0 / cpu_s, 4), "unit": "frames/s", "cores": torch.get_num_threads(),
-            "kind": "port",
-            "sample": f"1 frame pair at {w}x{h}, single run, PyTorch-CPU oracle (oracle/unet_oracle.py), "
-                      f"torch {torch.__version__}, {ncores} host threads",
-        }
-        result["parity"] = {
-            "max_abs_vs_cpu_ref": round(float((out.cpu() - ref).abs().max()), 6),
-            "rel_l2_vs_cpu_ref": round(float((out.cpu() - ref).norm() / ref.norm()), 6),
-            "fp32_path_max_abs_vs_cpu_ref": round(float((out32.cpu() - ref).abs().max()), 8),
-            "psnr_hip_vs_cpu_ref_u8_db": round(O.psnr_u8(ref_u8, hip_u8), 3),
-            "psnr_hip_vs_truth_db": round(O.psnr_u8(gt_u8, hip_u8), 4),
-            "psnr_cpu_vs_truth_db": round(O.psnr_u8(gt_u8, ref_u8), 4),
-            "out_absmax": round(float(ref.abs().max()), 4),
-        }
-        result["parity"]["psnr_delta_db"] = round(
-            abs(result["parity"]["psnr_hip_vs_truth_db"] - result["parity"]["psnr_cpu_vs_truth_db"]), 4)
-    print(json.dumps(result))
-    if dist is not None:
-        dist.destroy_process_group()
+    if cpu_baseline is not None:
+        result["cpu_baseline"] = cpu_baseline
+    if parity is not None:
+        result["parity"] = parity
+    if video_res is not None:
+        result["video_sharded"] = video_res
+    if tile_res is not None:
+        result["tile4k"] = tile_res
+    return result
 
 
 if __name__ == "__main__":

@@ -33,7 +33,39 @@ def strided_sample(t: torch.Tensor, n: int = 2048):
     return idx.numpy().astype(np.int64), flat[idx].numpy().astype(np.float32)
 
 
+RGB_WEIGHT_SEED = 77
+
+
+def gen_rgb():
+    """RGB 6->3 variant: the reference's own parametric
+    `UNet(n_channels=6, n_classes=3, bilinear=True)` (unet.py:66) on cat([frame1, frame2]) -- the
+    exact computation FrameInterpolationUNet.forward (unet.py:105-112) would do with that inner
+    network.  State-dict keys of the inner UNet are the seeded checkpoint's minus the `unet.` prefix."""
+    sys.path.insert(0, REF_DIR)
+    from unet import UNet  # the reference class (unet.py:65)
+
+    torch.set_num_threads(8)
+    sd = O.make_seeded_state_dict(RGB_WEIGHT_SEED, n_channels=6, n_classes=3)
+    inner = UNet(n_channels=6, n_classes=3, bilinear=True)
+    print("rgb load_state_dict:", inner.load_state_dict(
+        {k[len("unet."):]: v for k, v in sd.items()}, strict=True))
+    inner.eval()
+    for name, seed, b, h, w in (("rgb_b2_40x56", 31, 2, 40, 56), ("rgb_b1_33x47", 32, 1, 33, 47)):
+        f1, f2 = O.make_frames(seed, b, h, w, c=3)
+        with torch.no_grad():
+            out = inner(torch.cat([f1, f2], dim=1))
+        mine = O.unet_forward(sd, f1, f2)
+        print(f"{name}: out {tuple(out.shape)} std {out.std():.4f} min {out.min():.3f} max {out.max():.3f} "
+              f"|restatement-ref| {float((mine - out).abs().max()):.3e}")
+        np.savez_compressed(os.path.join(GOLD, f"out_{name}.npz"), seed=seed,
+                            weight_seed=RGB_WEIGHT_SEED, frame1=f1.numpy(), frame2=f2.numpy(),
+                            out=out.numpy())
+
+
 def main():
+    if "--rgb-only" in sys.argv:  # add the RGB fixtures without re-recording the others
+        os.makedirs(GOLD, exist_ok=True)
+        return gen_rgb()
     sys.path.insert(0, REF_DIR)
     from unet import FrameInterpolationUNet  # the reference class (unet.py:97)
 
@@ -143,6 +175,7 @@ def main():
     gt = O.postprocess_tensor(0.5 * (f1[:1] + f2[:1]))
     np.savez_compressed(os.path.join(GOLD, "post_b1_64x64.npz"),
                         out=out.numpy(), u8=u8, gt_u8=gt, psnr=np.float64(O.psnr_u8(gt, u8)))
+    gen_rgb()
     print("done; files:", sorted(os.listdir(GOLD)))
 
 

@@ -96,6 +96,55 @@ def make_seeded_state_dict(seed: int = 1234, n_channels: int = 2, n_classes: int
     return sd
 
 
+def make_interpolating_state_dict(seed: int = 4321, n_channels: int = 2, n_classes: int = 1,
+                                  perturb: float = 0.03):
+    """A checkpoint that actually interpolates, so that PSNR against a ground-truth middle frame
+    means something (a random-init network sits ~15 dB from any truth, which makes
+    |PSNR_a - PSNR_b| <= 0.05 dB vacuous).  Analytic part: the stem splits each input channel c
+    into relu(+x_c) and relu(-x_c) (centre tap, identity BatchNorm); those 2*n_channels feature
+    maps are carried unchanged through inc's second conv, the x1 skip, and up4's two convs
+    (identity centre taps; ReLU is the identity on non-negative maps); the 1x1 head recombines
+    them into 0.5 * (frame1 + frame2).  Everything else is the seeded random network of
+    make_seeded_state_dict, which runs through all 18 convs and is added to the output through
+    the remaining head weights, scaled so that it perturbs the result by ~`perturb` rms: every
+    layer and both skip / upsampled halves of every concat contribute to the output.
+    The carried maps receive no other inputs and the random maps may read them."""
+    sd = make_seeded_state_dict(seed, n_channels, n_classes)
+    cf = n_classes
+    assert n_channels == 2 * cf, "frame-pair network: n_channels == 2 * n_classes"
+    nk = 2 * n_channels  # carried maps: (+,-) of every input channel
+    one_m_eps = 1.0 - BN_EPS
+
+    def identity_bn(prefix, bn_i, rows):
+        sd[f"{prefix}.double_conv.{bn_i}.weight"][rows] = 1.0
+        sd[f"{prefix}.double_conv.{bn_i}.bias"][rows] = 0.0
+        sd[f"{prefix}.double_conv.{bn_i}.running_mean"][rows] = 0.0
+        sd[f"{prefix}.double_conv.{bn_i}.running_var"][rows] = one_m_eps
+
+    rows = slice(0, nk)
+    w = sd["unet.inc.double_conv.0.weight"]
+    w[rows] = 0.0
+    for c in range(n_channels):
+        w[2 * c, c, 1, 1] = 1.0
+        w[2 * c + 1, c, 1, 1] = -1.0
+    identity_bn("unet.inc", 1, rows)
+    for prefix, conv_i, bn_i in (("unet.inc", 3, 4), ("unet.up4.conv", 0, 1), ("unet.up4.conv", 3, 4)):
+        w = sd[f"{prefix}.double_conv.{conv_i}.weight"]
+        w[rows] = 0.0
+        for k in range(nk):
+            w[k, k, 1, 1] = 1.0  # up4.conv.0: input channel k of cat([x1, up]) is x1's channel k
+        identity_bn(prefix, bn_i, rows)
+    hw = sd["unet.outc.conv.weight"]
+    hw *= perturb / 0.25  # the seeded head gives ~0.25 rms on the seeded features
+    hw[:, :nk] = 0.0
+    for o in range(cf):  # output channel o = mean of channel o of frame1 and of frame2
+        for c in (o, cf + o):
+            hw[o, 2 * c, 0, 0] = 0.5
+            hw[o, 2 * c + 1, 0, 0] = -0.5
+    sd["unet.outc.conv.bias"].zero_()
+    return sd
+
+
 def make_frames(seed: int, b: int, h: int, w: int, c: int = 1):
     """Uniform [-1,1] synthetic frame pair, seeded (SURVEY 8d 'Config 1/2')."""
     g = torch.Generator().manual_seed(seed)

@@ -45,12 +45,14 @@ def _worker(rank, world, port, n_frames, shape, q):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("n_frames", [2, 3, 8, 11])
-def test_sharded_video_world2(n_frames):
+@pytest.mark.parametrize("n_frames,world", [(2, 2), (3, 2), (8, 2), (11, 2), (1, 2), (23, 3)])
+def test_sharded_video_world2(n_frames, world):
+    """batch=3 pairs per sub-batch: 11 frames on 2 ranks = 2 pipelined steps per rank, 23 frames on
+    3 ranks = 3 steps with a ragged last rank (8 + 8 + 6 pairs)."""
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, n_frames, (6, 10), q)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, n_frames, (6, 10), q)) for r in range(world)]
     for p in procs:
         p.start()
     for p in procs:

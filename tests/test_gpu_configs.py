@@ -1,0 +1,184 @@
+"""GPU (MI355X): the BASELINE.json configs and kernel paths that round 1's GPU suite did not
+exercise (VERDICT r01 "Next round" item 1), all through the C ABI:
+
+  config 2   B=16 256x256 fp32 -- a different kernel path from the B=1 golden (the split-K
+             decision depends on the number of workgroups, csrc/fiunet.hip launch_conv_maybe_split)
+  config 4   the video loop at FULL frame size (1080p), short length, device and host variants
+  RGB bf16   conv3x3_first_kernel<bf16,3> + EPI_HEAD3 in bf16, fused and unfused, odd size
+  RGB fp32   pinned to the reference's own UNet(6,3) outputs (tests/golden/out_rgb_*.npz)
+  PSNR       |PSNR_hip - PSNR_cpu| <= 0.05 dB against a TRUE middle frame, on a checkpoint that
+             actually interpolates (oracle.make_interpolating_state_dict), at 256x256 and 1080p
+Tolerances as in test_gpu_parity.py; the bf16 contract is restated where it is used.
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import ai_based_frame_interpolation_amd as P
+from ai_based_frame_interpolation_amd import synthetic as S
+from oracle import unet_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+FP32_TOL = 1e-3
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available(), "GPU tests need an MI355X"
+    return torch.device("cuda:0")
+
+
+@pytest.fixture(scope="module")
+def model(dev, seeded_sd):
+    m = P.FrameInterpolationUNet(bilinear=True)
+    m.load_state_dict(seeded_sd)
+    return m.to(dev).eval()
+
+
+def test_config2_batch16_256_fp32(model, dev, seeded_sd, golden_dir):
+    """BASELINE configs[1]: 16 pairs of 256x256, fp32 HIP path, vs the oracle on all 16 and vs the
+    reference's own 256x256 output (golden) on the item that carries the golden pair."""
+    g = np.load(os.path.join(golden_dir, "out_b1_256x256.npz"))
+    f1, f2 = O.make_frames(1, 16, 256, 256)  # seed 1
+    k = 11
+    f1[k], f2[k] = torch.from_numpy(g["frame1"])[0], torch.from_numpy(g["frame2"])[0]
+    ref = O.unet_forward(seeded_sd, f1, f2)
+    model.precision = "fp32"
+    model.set_options()
+    out = model(f1.to(dev), f2.to(dev)).cpu()
+    d = (out - ref).abs().max().item()
+    assert d <= FP32_TOL and d <= 1e-4 * max(1.0, ref.abs().max().item()), d
+    dg = np.abs(out[k].numpy() - g["out"][0]).max()
+    assert dg <= FP32_TOL and dg <= 1e-4 * max(1.0, np.abs(g["out"]).max()), dg
+    # batch / position invariance at this size: item k alone takes the B=1 (split-K) path
+    single = model(f1[k:k + 1].to(dev), f2[k:k + 1].to(dev)).cpu()
+    assert (single[0] - out[k]).abs().max().item() <= 1e-5
+    model.precision = "bf16"
+    out16 = model(f1.to(dev), f2.to(dev)).cpu()
+    assert ((out16 - ref).norm() / ref.norm()).item() <= 2e-2
+
+
+def test_config4_video_loop_full_size_1080p(model, dev, seeded_sd):
+    """BASELINE configs[3] at full frame size, short length: 17 synthetic 1080p uint8 frames through
+    the device-resident and the host-resident loops (bit-equal to each other and to per-pair
+    forward_u8); one pair against the oracle's post-processed frame."""
+    n, h, w = 17, 1080, 1920
+    frames = S.moving_frames(0, n, h, w, device="cpu", seed=7)
+    assert frames.shape == (n, h, w) and frames.dtype == torch.uint8
+    model.precision = "bf16"
+    model.set_options()
+    dseq = P.interpolate_sequence(model, frames.to(dev), batch=8)
+    hseq = P.interpolate_sequence_host(model, frames, batch=8)
+    assert dseq.shape == (2 * n - 1, h, w)
+    assert torch.equal(dseq.cpu(), hseq)
+    assert torch.equal(dseq[0::2].cpu(), frames)
+    for i in (0, 7, 8, 15):  # first/last of a full chunk, first of the ragged last chunk, last pair
+        mid = model.forward_u8(frames[i][None, None].to(dev), frames[i + 1][None, None].to(dev))[0, 0]
+        assert torch.equal(dseq[2 * i + 1], mid), i
+    # one pair vs the oracle (CPU, ~20-30 s): fp32 path within +-1 code on <= 1e-3 of the pixels,
+    # bf16 path >= 45 dB from the oracle's frame
+    i = 8
+    fa, fb = O.preprocess_array(frames[i].numpy()), O.preprocess_array(frames[i + 1].numpy())
+    want = O.postprocess_tensor(O.unet_forward(seeded_sd, fa, fb))
+    model.precision = "fp32"
+    got32 = model.forward_u8(frames[i][None, None].to(dev), frames[i + 1][None, None].to(dev))[0, 0].cpu().numpy()
+    diff = np.abs(got32.astype(int) - want.astype(int))
+    assert diff.max() <= 1 and (diff != 0).mean() <= 1e-3, (diff.max(), (diff != 0).mean())
+    assert O.psnr_u8(want, dseq[2 * i + 1].cpu().numpy()) >= 45.0
+    model.precision = "fp32"
+
+
+def _rgb_model(dev, seed=77, precision="fp32"):
+    sd = O.make_seeded_state_dict(seed, n_channels=6, n_classes=3)
+    m = P.FrameInterpolationUNet(bilinear=True, frame_channels=3, precision=precision)
+    m.load_state_dict(sd)
+    return m.to(dev).eval(), sd
+
+
+@pytest.mark.parametrize("name", ["rgb_b2_40x56", "rgb_b1_33x47"])
+def test_rgb_fp32_matches_reference_unet_6_3(dev, golden_dir, name):
+    g = np.load(os.path.join(golden_dir, f"out_{name}.npz"))
+    m, _ = _rgb_model(dev, int(g["weight_seed"]))
+    f1, f2, ref = torch.from_numpy(g["frame1"]), torch.from_numpy(g["frame2"]), torch.from_numpy(g["out"])
+    for unfused in (False, True):
+        m.set_options(unfused=unfused)
+        out = m(f1.to(dev), f2.to(dev)).cpu()
+        d = (out - ref).abs().max().item()
+        assert out.shape == ref.shape and d <= FP32_TOL and d <= 1e-4 * max(1.0, ref.abs().max().item()), d
+
+
+def test_rgb_bf16_odd_size_fused_unfused_oracle(dev):
+    """conv3x3_first_kernel<bf16,3> and the 3-class fused head in bf16 (never run by round 1's
+    tests), at an odd size (floor-pool + asymmetric F.pad), fused vs unfused vs oracle."""
+    m, sd = _rgb_model(dev, 77, "bf16")
+    f1, f2 = O.make_frames(33, 2, 45, 71, c=3)
+    ref = O.unet_forward(sd, f1, f2)
+    rng = (ref.max() - ref.min()).item()
+    outs = {}
+    for unfused in (False, True):
+        m.set_options(unfused=unfused)
+        acts, out = m.debug_activations(f1.to(dev), f2.to(dev))
+        outs[unfused] = (acts, out.cpu())
+        o = outs[unfused][1]
+        assert o.shape == (2, 3, 45, 71) and torch.isfinite(o).all()
+        assert ((o - ref).norm() / ref.norm()).item() <= 2e-2
+        assert (o - ref).abs().max().item() <= 0.04 * rng
+    m.set_options()
+    # RGB has no fused stem, so in bf16 all 18 stage outputs are bit-identical fused vs unfused
+    for k in outs[False][0]:
+        assert torch.equal(outs[False][0][k], outs[True][0][k]), k
+    assert (outs[False][1] - outs[True][1]).abs().max().item() <= 2e-2
+    # the uint8 path on RGB frames
+    gen = torch.Generator().manual_seed(5)
+    a = torch.randint(0, 256, (1, 3, 45, 71), dtype=torch.uint8, generator=gen)
+    b = torch.randint(0, 256, (1, 3, 45, 71), dtype=torch.uint8, generator=gen)
+    got = m.forward_u8(a.to(dev), b.to(dev)).cpu().numpy()
+    fa = torch.stack([O.preprocess_array(a[0, c].numpy())[0, 0] for c in range(3)])[None]
+    fb = torch.stack([O.preprocess_array(b[0, c].numpy())[0, 0] for c in range(3)])[None]
+    want = np.stack([O.postprocess_tensor(O.unet_forward(sd, fa, fb)[:, c:c + 1]) for c in range(3)])[None]
+    assert O.psnr_u8(want, got) >= 35.0
+
+
+@pytest.mark.parametrize("h,w", [(256, 256), (1080, 1920)])
+def test_psnr_within_0p05_db_of_cpu_reference(dev, h, w):
+    """north_star: "PSNR within 0.05 dB of the CPU reference".  Frames t and t+2 of a synthetic
+    scene in, frame t+1 is the truth; the checkpoint really interpolates (>= 30 dB), so a bf16
+    error of a couple of uint8 codes WOULD move the PSNR by more than the bound."""
+    sd = O.make_interpolating_state_dict()
+    m = P.FrameInterpolationUNet(bilinear=True)
+    m.load_state_dict(sd)
+    m = m.to(dev).eval()
+    a, truth, c = S.triplet(h, w, device="cpu", seed=3)
+    fa, fc = O.preprocess_array(a.numpy()), O.preprocess_array(c.numpy())
+    ref_u8 = O.postprocess_tensor(O.unet_forward(sd, fa, fc))
+    psnr_cpu = O.psnr_u8(truth.numpy(), ref_u8)
+    assert psnr_cpu >= 30.0, psnr_cpu
+    for prec in ("fp32", "bf16"):
+        m.precision = prec
+        hip_u8 = m.forward_u8(a[None, None].to(dev), c[None, None].to(dev))[0, 0].cpu().numpy()
+        psnr_hip = O.psnr_u8(truth.numpy(), hip_u8)
+        assert abs(psnr_hip - psnr_cpu) <= 0.05, (prec, psnr_hip, psnr_cpu)
+        assert O.psnr_u8(ref_u8, hip_u8) >= (60.0 if prec == "fp32" else 45.0)
+    # sensitivity check: the criterion is not vacuous -- two uint8 codes of error break it
+    noisy = np.clip(ref_u8.astype(int) + np.random.default_rng(0).integers(-3, 4, ref_u8.shape), 0, 255)
+    assert abs(O.psnr_u8(truth.numpy(), noisy.astype(np.uint8)) - psnr_cpu) > 0.05
+
+
+def test_bf16_error_contract_on_bench_network(dev):
+    """bench.py's own random-init network (He-scaled convs, wide BatchNorm statistics) is harder on
+    bf16 than the seeded test checkpoint: the contract stated in DESIGN.md section 4 is rel-L2 <= 6e-2
+    and uint8 PSNR(hip, cpu reference) >= 45 dB (measured 4.3e-2 / 51.9 dB at 1080p)."""
+    import bench
+    model = bench.make_bench_model("bf16").to(dev).eval()
+    sd = {k: v.detach().cpu() for k, v in model.state_dict().items()}
+    f1, f2 = O.make_frames(2, 1, 270, 480)
+    ref = O.unet_forward(sd, f1, f2)
+    out = model(f1.to(dev), f2.to(dev)).cpu()
+    assert ((out - ref).norm() / ref.norm()).item() <= 6e-2
+    assert O.psnr_u8(O.postprocess_tensor(ref), O.postprocess_tensor(out)) >= 45.0
+    model.precision = "fp32"
+    out32 = model(f1.to(dev), f2.to(dev)).cpu()
+    assert (out32 - ref).abs().max().item() <= FP32_TOL
