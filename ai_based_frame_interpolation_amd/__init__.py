@@ -6,11 +6,13 @@ from .inference import (  # noqa: F401
     FrameInterpolator, generate_multiple_intermediate_frames, interpolate_frames,
     interpolate_sequence, interpolate_sequence_host, load_model, postprocess_image, preprocess_image,
 )
-from . import evaluation, metrics, tiling, video  # noqa: F401
+from .serving import InterpolationService  # noqa: F401
+from . import evaluation, metrics, serving, synthetic, tiling, video  # noqa: F401
 
 __all__ = [
     "FrameInterpolationUNet", "GraphedForward", "UNet", "count_parameters", "FrameInterpolator",
     "generate_multiple_intermediate_frames", "interpolate_frames", "interpolate_sequence",
     "interpolate_sequence_host",
     "load_model", "postprocess_image", "preprocess_image", "evaluation", "metrics", "tiling", "video",
+    "InterpolationService", "serving", "synthetic",
 ]

@@ -88,6 +88,7 @@ struct ConvArgs {
     // slice s stores its raw fp32 partial sums to kslab[s][B*H*W][Cout]; splitk_finalize_kernel adds
     // the slices in order (deterministic) and applies scale/shift/ReLU.
     int ksplit;
+    int legacy;          // host side only: keep to conv3x3_mfma_kernel (FIUNET_OPT_LEGACY_TILES, A/B runs)
     float* kslab;
     unsigned long long* stamp;  // diagnostic builds (-DFIUNET_STAMP) only: 8 cycle sums per wave
     const float* head_w; // fused 1x1 head: [head_nc][64]

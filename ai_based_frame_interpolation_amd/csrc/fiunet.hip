@@ -9,9 +9,11 @@
 // gfx950 only; no CPU fallback: every entry point either launches HIP kernels or returns an error.
 #include "../../include/fiunet.h"
 #include "pointwise.hip.h"
+#include "conv3x3_pair.hip.h"
 #include "metrics.hip.h"
 
 #include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <cstdio>
 #include <cstring>
@@ -97,7 +99,19 @@ struct Plan {
     size_t total;
 };
 
-bool make_plan(int B, int H, int W, int precision, Plan& p)
+// Workspace plan.  The reference, under no_grad, frees every non-skip tensor as soon as its consumer
+// has run (model/unet.py:84-95 keeps only x1..x4 alive); here the same liveness is turned into a
+// static layout: every buffer gets the interval [stage that writes it, last stage that reads it]
+// (stage i = conv i of the 18) and buffers whose intervals do not overlap share bytes (first-fit
+// over the buffers in order of their first stage).  B=8 1080p bf16 needs 5.9 GB this way instead of
+// the 14.6 GB of one private buffer per tensor.  `keep_all` (FIUNET_OPT_KEEP_ALL, the debug
+// read-back) pins every activation to the end; `unfused` adds the ablation path's concat scratch;
+// the fused stem / fused head leave activations 0 / 17 out altogether.
+struct PlanOpts {
+    bool keep_all = false, unfused = false, fused_stem = false, fused_head = false;
+};
+
+bool make_plan(int B, int H, int W, int precision, const PlanOpts& o, Plan& p)
 {
     if (B < 1 || H < 16 || W < 16) return false;
     // the kernels address a pixel record inside one image plane with 32 bits: H*W*64 B < 4 GiB.
@@ -106,20 +120,47 @@ bool make_plan(int B, int H, int W, int precision, Plan& p)
     const size_t es = precision == FIUNET_BF16 ? 2 : 4;
     p.hs[0] = H; p.ws[0] = W;
     for (int k = 1; k < 5; ++k) { p.hs[k] = p.hs[k - 1] / 2; p.ws[k] = p.ws[k - 1] / 2; }
-    size_t off = 0;
+    struct Buf { size_t bytes; int first, last; size_t* off; };
+    std::vector<Buf> bufs;
+    const int END = NCONV;  // "still live after the last conv" (the unfused head, the debug read-back)
     for (int i = 0; i < NCONV; ++i) {
-        p.act_off[i] = off;
-        off += align256((size_t)B * p.hs[kLevel[i]] * p.ws[kLevel[i]] * kCout[i] * es);
+        p.act_off[i] = 0;
+        if ((i == 0 && o.fused_stem) || (i == NCONV - 1 && o.fused_head)) continue;  // never materialised
+        int last = i;  // conv j reads act i as its direct / skip source (kSrc0) or low-res source (kSrc1)
+        for (int j = i + 1; j < NCONV; ++j)
+            if (kSrc0[j] == i || kSrc1[j] == i) last = j;
+        if (i == NCONV - 1 || o.keep_all) last = END;
+        bufs.push_back({align256((size_t)B * p.hs[kLevel[i]] * p.ws[kLevel[i]] * kCout[i] * es), i, last,
+                        &p.act_off[i]});
     }
-    for (int k = 0; k < 4; ++k) {
-        p.pool_off[k] = off;
-        off += align256((size_t)B * p.hs[k + 1] * p.ws[k + 1] * kCout[2 * k + 1] * es);
+    for (int k = 0; k < 4; ++k) {  // MaxPool2d(2) of x1..x4: written by conv 2k+1, read by conv 2k+2
+        bufs.push_back({align256((size_t)B * p.hs[k + 1] * p.ws[k + 1] * kCout[2 * k + 1] * es), 2 * k + 1,
+                        o.keep_all ? END : 2 * k + 2, &p.pool_off[k]});
     }
-    p.scratch_off = off;  // ablation path: concat tensor (<= 128 ch at level 0)
-    off += align256((size_t)B * H * W * 128 * es);
-    p.slab_off = off;
-    off += kSlabBytes;
-    p.total = off;
+    p.scratch_off = 0;
+    if (o.unfused)  // ablation path: concat tensor (<= 128 ch at level 0), rewritten by every Up block
+        bufs.push_back({align256((size_t)B * H * W * 128 * es), 0, END, &p.scratch_off});
+    bufs.push_back({kSlabBytes, 0, END, &p.slab_off});  // split-K partial sums (small problems)
+    std::stable_sort(bufs.begin(), bufs.end(), [](const Buf& a, const Buf& b) { return a.first < b.first; });
+    struct Live { size_t off, bytes; int last; };
+    std::vector<Live> live;
+    size_t total = 0;
+    for (const Buf& b : bufs) {
+        // buffers whose last reader ran before this one's writer are dead (a conv never reads and
+        // writes the same bytes: its sources are live through its own stage)
+        live.erase(std::remove_if(live.begin(), live.end(), [&](const Live& l) { return l.last < b.first; }),
+                   live.end());
+        std::sort(live.begin(), live.end(), [](const Live& a, const Live& c) { return a.off < c.off; });
+        size_t off = 0;
+        for (const Live& l : live) {
+            if (off + b.bytes <= l.off) break;
+            off = std::max(off, l.off + l.bytes);
+        }
+        *b.off = off;
+        live.push_back({off, b.bytes, b.last});
+        total = std::max(total, off + b.bytes);
+    }
+    p.total = total;
     return true;
 }
 
@@ -147,6 +188,9 @@ struct fiunet_ctx {
 };
 
 namespace {
+
+// which activations a forward of this context materialises (must agree with forward_impl)
+PlanOpts plan_opts(const fiunet_ctx* ctx, int H, int W, int precision);
 
 int dev_upload(fiunet_ctx* ctx, const void* host, size_t bytes, void** out)
 {
@@ -183,20 +227,55 @@ int launch_conv_cfg(ConvArgs a, hipStream_t s)
     const long long nblk = (long long)a.B * a.tilesX * a.tilesY * a.nct * (EPI == EPI_SPLITK ? a.ksplit : 1);
     if (nblk <= 0 || nblk > 0x7fffffffLL) return fail(FIUNET_ERR_INVALID_ARG, "conv grid too large");
     // > 64 KiB of dynamic LDS needs the opt-in attribute, once per kernel and device
-    static bool lds_attr_set[64] = {};
+    static std::atomic<bool> lds_attr_set[64];  // a duplicate hipFuncSetAttribute is harmless
     int dev = 0;
     HIP_TRY(hipGetDevice(&dev));
-    if (dev >= 0 && dev < 64 && !lds_attr_set[dev]) {
+    if (dev >= 0 && dev < 64 && !lds_attr_set[dev].load(std::memory_order_acquire)) {
         HIP_TRY(hipFuncSetAttribute(
             reinterpret_cast<const void*>(&conv3x3_mfma_kernel<T, BN, TH, TW, MODE, EPI>),
             hipFuncAttributeMaxDynamicSharedMemorySize, Tile::LDS_BYTES));
-        lds_attr_set[dev] = true;
+        lds_attr_set[dev].store(true, std::memory_order_release);
     }
     hipLaunchKernelGGL((conv3x3_mfma_kernel<T, BN, TH, TW, MODE, EPI>), dim3((unsigned)nblk),
                        dim3(256), Tile::LDS_BYTES, s, a);
     HIP_TRY(hipGetLastError());
     return FIUNET_OK;
 }
+
+// One 8-wave workgroup per CU on two pixel tiles with a shared weight ring (conv3x3_pair.hip.h).
+template <typename T, int BN, int TH, int TW, int EPI>
+int launch_pair_cfg(ConvArgs a, hipStream_t s)
+{
+    using Tile = PairTile<BN, TH, TW>;
+    if (g_name_out) {
+        char buf[128];
+        std::snprintf(buf, sizeof buf, "conv3x3_pair_kernel<%s,%d,%d,%d,%d>",
+                      sizeof(T) == 2 ? "bf16" : "f32", BN, TH, TW, EPI);
+        *g_name_out = buf;
+    }
+    a.tilesX = (a.W + TW - 1) / TW;
+    a.tilesY = (a.H + TH - 1) / TH;
+    a.nct = a.Cout / BN;
+    const long long ntiles = (long long)a.B * a.tilesX * a.tilesY;
+    const long long nblk = (ntiles + 1) / 2 * a.nct;
+    if (nblk <= 0 || nblk > 0x7fffffffLL) return fail(FIUNET_ERR_INVALID_ARG, "conv grid too large");
+    static std::atomic<bool> lds_attr_set[64];
+    int dev = 0;
+    HIP_TRY(hipGetDevice(&dev));
+    if (dev >= 0 && dev < 64 && !lds_attr_set[dev].load(std::memory_order_acquire)) {
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_pair_kernel<T, BN, TH, TW, EPI>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, Tile::LDS_BYTES));
+        lds_attr_set[dev].store(true, std::memory_order_release);
+    }
+    hipLaunchKernelGGL((conv3x3_pair_kernel<T, BN, TH, TW, EPI>), dim3((unsigned)nblk), dim3(512),
+                       Tile::LDS_BYTES, s, a);
+    HIP_TRY(hipGetLastError());
+    return FIUNET_OK;
+}
+
+// pair kernel: direct sources, plain / pooled epilogue, enough tile pairs to fill the 256 CUs
+template <typename T, int BN, int TH, int TW, int MODE, int EPI>
+constexpr bool pair_capable() { return MODE == SRC_DIRECT && (EPI == EPI_PLAIN || EPI == EPI_POOL) && BN == 128; }
 
 inline unsigned grid_for(size_t n);
 
@@ -230,6 +309,11 @@ int launch_conv_maybe_split(ConvArgs a, hipStream_t s)
             return FIUNET_OK;
         }
     }
+    if constexpr (pair_capable<T, BN, TH, TW, MODE, EPI>()) {
+        const long long ntiles = (long long)a.B * ((a.W + TW - 1) / TW) * ((a.H + TH - 1) / TH);
+        if (!a.legacy && (ntiles + 1) / 2 * (a.Cout / BN) >= 256)
+            return launch_pair_cfg<T, BN, TH, TW, EPI>(a, s);
+    }
     return launch_conv_cfg<T, BN, TH, TW, MODE, EPI>(a, s);
 }
 
@@ -245,6 +329,19 @@ inline bool prefer_wide(int H, int W, int THw, int TWw, int THn, int TWn)
 {
     const long long wide = padded_area(H, W, THw, TWw), narrow = padded_area(H, W, THn, TWn);
     return wide * 32 <= narrow * 33;
+}
+
+PlanOpts plan_opts(const fiunet_ctx* ctx, int H, int W, int precision)
+{
+    PlanOpts o;
+    o.keep_all = ctx->flags & FIUNET_OPT_KEEP_ALL;
+    o.unfused = ctx->flags & FIUNET_OPT_UNFUSED;
+    // bf16 gray network: the stem is evaluated inside conv 1's gather (SRC_STEM, 16x32 tiles only),
+    // unless the ablation path or the debug read-back needs its output in HBM
+    o.fused_stem = precision == FIUNET_BF16 && ctx->cf == 1 && !o.unfused && !o.keep_all &&
+                   ctx->stem_w_split != nullptr && prefer_wide(H, W, 16, 32, 32, 16);
+    o.fused_head = !o.unfused && !o.keep_all;  // OutConv reduced in the last conv's epilogue
+    return o;
 }
 
 template <typename T, int MODE, int EPI> int launch_conv_shape(const ConvArgs& a, hipStream_t s)
@@ -309,9 +406,12 @@ int forward_impl(fiunet_ctx* ctx, const float* f1, const float* f2, float* out, 
     }
     // bf16 gray network: the stem is evaluated inside conv 1's gather (SRC_STEM), unless the
     // ablation path or the debug readback needs its output in HBM
-    const bool fuse_stem = bf16 && ctx->cf == 1 && !unfused && ctx->stem_w_split != nullptr &&
-                           prefer_wide(H, W, 16, 32, 32, 16);
-    const bool run_stem = !fuse_stem || (ctx->flags & FIUNET_OPT_KEEP_ALL);
+    const PlanOpts po = plan_opts(ctx, H, W, bf16 ? FIUNET_BF16 : FIUNET_FP32);
+    // with KEEP_ALL the stem also runs as its own kernel (tap 0 in HBM) while conv 1 still
+    // evaluates it in its gather: the fused numerics are what the read-back must show downstream
+    const bool fuse_stem = po.fused_stem || (bf16 && ctx->cf == 1 && !unfused && ctx->stem_w_split != nullptr &&
+                                             prefer_wide(H, W, 16, 32, 32, 16));
+    const bool run_stem = !po.fused_stem;
     // conv 0: fp32 stem (unet.py:72, first conv of inc)
     if (run_stem) {
         const ConvWeights& cw = ctx->conv[0];
@@ -345,6 +445,7 @@ int forward_impl(fiunet_ctx* ctx, const float* f1, const float* f2, float* out, 
         a.relu = 1;
         a.zero_page = ctx->zero_page;
         a.ksplit = 1;
+        a.legacy = (ctx->flags & FIUNET_OPT_LEGACY_TILES) ? 1 : 0;
         // the last conv is never K-split: its fused-head form cannot be, and the ablation path must
         // accumulate in the same order to stay bit-identical with it
         a.kslab = i == NCONV - 1 ? nullptr : (float*)(ws + p.slab_off);
@@ -585,7 +686,8 @@ int fiunet_load_weights(fiunet_ctx* ctx, int n, const char* const* names,
 size_t fiunet_workspace_bytes(const fiunet_ctx* ctx, int B, int H, int W, int precision)
 {
     Plan p;
-    if (!ctx || (precision != FIUNET_FP32 && precision != FIUNET_BF16) || !make_plan(B, H, W, precision, p)) {
+    if (!ctx || (precision != FIUNET_FP32 && precision != FIUNET_BF16) ||
+        !make_plan(B, H, W, precision, plan_opts(ctx, H, W, precision), p)) {
         g_err = "fiunet_workspace_bytes: bad arguments";
         return 0;
     }
@@ -617,7 +719,7 @@ int fiunet_forward_strip(fiunet_ctx* ctx, const float* frame1, const float* fram
     if (H < 16 || W < 16)
         return fail(FIUNET_ERR_BAD_SHAPE, "H and W must be >= 16 (four 2x2 max-pools)");
     Plan p;
-    if (!make_plan(B, H, W, precision, p))
+    if (!make_plan(B, H, W, precision, plan_opts(ctx, H, W, precision), p))
         return fail(FIUNET_ERR_BAD_SHAPE, "H*W must be below 2^26 pixels per call: cut taller frames into "
                                           "bands (fiunet_forward_strip)");
     if (workspace_bytes < p.total) return fail(FIUNET_ERR_WORKSPACE, "workspace too small");
@@ -802,7 +904,11 @@ int fiunet_debug_read_activation(fiunet_ctx* ctx, const void* workspace, int B, 
     if (!ctx || !workspace || !dst || tap < 0 || tap >= NCONV)
         return fail(FIUNET_ERR_INVALID_ARG, "bad argument");
     Plan p;
-    if (!make_plan(B, H, W, precision, p)) return fail(FIUNET_ERR_BAD_SHAPE, "bad shape");
+    if (!(ctx->flags & FIUNET_OPT_KEEP_ALL))
+        return fail(FIUNET_ERR_INVALID_ARG, "read-back needs FIUNET_OPT_KEEP_ALL set for the forward: without it "
+                                            "activations share workspace bytes and are overwritten");
+    if (!make_plan(B, H, W, precision, plan_opts(ctx, H, W, precision), p))
+        return fail(FIUNET_ERR_BAD_SHAPE, "bad shape");
     const int C = kCout[tap], h = p.hs[kLevel[tap]], w = p.ws[kLevel[tap]];
     if (out_dims) { out_dims[0] = C; out_dims[1] = h; out_dims[2] = w; }
     const size_t n = (size_t)B * C * h * w;

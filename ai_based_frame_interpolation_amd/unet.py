@@ -47,16 +47,58 @@ class _Holder(nn.Module):
         raise RuntimeError("parameter holder: the forward runs in the HIP kernels, not in torch")
 
 
+class _Slot(nn.Module):
+    """Place-holder child at a position where the reference has a tensor-less module (ReLU,
+    MaxPool2d, Upsample): keeps `named_modules()`, integer indexing and `len()` of the holders
+    identical to the reference's nn.Sequential / Up, while owning no tensors (state-dict unchanged).
+    The op itself is fused into the neighbouring HIP conv kernel."""
+
+    def __init__(self, what: str):
+        super().__init__()
+        self.what = what
+
+    def extra_repr(self):
+        return f"{self.what} (fused into the HIP conv kernels)"
+
+    def forward(self, *a, **k):  # pragma: no cover
+        raise RuntimeError(f"{self.what}: fused into the HIP kernels, not callable on its own")
+
+
+class _Seq(nn.ModuleDict):
+    """ModuleDict keyed "0".."n-1" that also indexes like nn.Sequential (int and slice), so
+    `model.unet.inc.double_conv[0].weight` and `down1.maxpool_conv[1]` work as on the reference
+    (/root/reference/model/unet.py:11-18, :27-30)."""
+
+    def __getitem__(self, idx):
+        if isinstance(idx, slice):
+            keys = list(self._modules.keys())[idx]
+            return _Seq({k: self._modules[k] for k in keys})
+        if isinstance(idx, int):
+            n = len(self._modules)
+            if not -n <= idx < n:
+                raise IndexError(f"index {idx} is out of range")
+            return list(self._modules.values())[idx % n]
+        return super().__getitem__(idx)
+
+    def __iter__(self):  # nn.Sequential iterates over modules, ModuleDict over keys
+        return iter(self._modules.values())
+
+    def forward(self, *a, **k):  # pragma: no cover
+        raise RuntimeError("parameter holder: the forward runs in the HIP kernels, not in torch")
+
+
 def _double_conv(cin: int, cout: int, mid: int | None = None) -> _Holder:
-    """Holder with `.double_conv.{0,1,3,4}` like DoubleConv (unet.py:5-18); slots 2 and 5
-    (ReLU) own no tensors."""
+    """Holder with `.double_conv[0..5]` like DoubleConv (unet.py:5-18): conv, BN, ReLU, conv, BN,
+    ReLU; slots 2 and 5 (ReLU) own no tensors."""
     mid = mid or cout
     h = _Holder()
-    h.double_conv = nn.ModuleDict({
+    h.double_conv = _Seq({
         "0": nn.Conv2d(cin, mid, kernel_size=3, padding=1, bias=False),
         "1": nn.BatchNorm2d(mid),
+        "2": _Slot("ReLU(inplace=True)"),
         "3": nn.Conv2d(mid, cout, kernel_size=3, padding=1, bias=False),
         "4": nn.BatchNorm2d(cout),
+        "5": _Slot("ReLU(inplace=True)"),
     })
     return h
 
@@ -76,10 +118,11 @@ class UNet(_Holder):
         self.inc = _double_conv(n_channels, 64)
         for name, cin, cout in _ENCODER:
             d = _Holder()
-            d.maxpool_conv = nn.ModuleDict({"1": _double_conv(cin, cout)})
+            d.maxpool_conv = _Seq({"0": _Slot("MaxPool2d(2)"), "1": _double_conv(cin, cout)})
             setattr(self, name, d)
         for name, cin, cout in _DECODER:
             u = _Holder()
+            u.up = _Slot("Upsample(scale_factor=2, mode='bilinear', align_corners=True)")
             u.conv = _double_conv(cin, cout, cin // 2)
             setattr(self, name, u)
         self.outc = _Holder()
@@ -105,14 +148,40 @@ class FrameInterpolationUNet(nn.Module):
             raise ValueError(f"precision must be one of {sorted(_PRECISIONS)}")
         self._ctx = None          # _native.Context, per device
         self._ctx_dirty = True    # weights on the device are stale w.r.t. the parameters
-        self._ws = None           # cached workspace tensor
-        self._ws_key = None
+        self._weights_gen = 0     # bumped at every upload (GraphedForward re-captures on change)
+        self._tracked = None      # parameters + buffers whose (version, data_ptr) are fingerprinted
+        self._fingerprint = None
+        self._ws = None           # cached workspace tensor (kept at the largest size seen)
         self._options = 0
 
     # -- keep the device copy of the weights in sync with the nn.Module state --------------
+    # Like the reference nn.Module, a forward always uses the LIVE parameters: besides the explicit
+    # hooks below, every forward compares a cheap fingerprint (autograd version counter + storage
+    # pointer of each parameter and buffer) with the one recorded at the last upload, so in-place
+    # edits (`p.add_(..)`, `p.data = ..`, `model.unet.load_state_dict(..)`) are picked up too.
     def _apply(self, fn, *a, **k):
         self._ctx_dirty = True
+        self._tracked = None
         return super()._apply(fn, *a, **k)
+
+    def _current_fingerprint(self):
+        if self._tracked is None:
+            self._tracked = [t for t in list(self.parameters()) + list(self.buffers())]
+        return tuple((t._version, t.data_ptr()) for t in self._tracked)
+
+    # the HIP context holds raw pointers: never pickled / deep-copied with the module
+    def __getstate__(self):
+        st = self.__dict__.copy()
+        st["_ctx"], st["_ws"], st["_tracked"], st["_fingerprint"], st["_ctx_dirty"] = None, None, None, None, True
+        return st
+
+    def __deepcopy__(self, memo):
+        import copy
+        new = self.__class__.__new__(self.__class__)
+        memo[id(self)] = new
+        for k, v in self.__getstate__().items():
+            new.__dict__[k] = copy.deepcopy(v, memo)
+        return new
 
     def load_state_dict(self, *a, **k):
         self._ctx_dirty = True
@@ -122,8 +191,9 @@ class FrameInterpolationUNet(nn.Module):
         """Call after editing parameters in place so the next forward re-uploads them."""
         self._ctx_dirty = True
 
-    def set_options(self, *, unfused: bool = False, keep_all: bool = False):
-        self._options = (_native.OPT_UNFUSED if unfused else 0) | (_native.OPT_KEEP_ALL if keep_all else 0)
+    def set_options(self, *, unfused: bool = False, keep_all: bool = False, legacy_tiles: bool = False):
+        self._options = ((_native.OPT_UNFUSED if unfused else 0) | (_native.OPT_KEEP_ALL if keep_all else 0)
+                         | (_native.OPT_LEGACY_TILES if legacy_tiles else 0))
         if self._ctx is not None:
             self._ctx.set_options(self._options)
 
@@ -134,19 +204,22 @@ class FrameInterpolationUNet(nn.Module):
                 self._ctx.close()
             self._ctx = _native.Context(idx, self.frame_channels, True)
             self._ctx_dirty = True
-        if self._ctx_dirty:
+        fp = self._current_fingerprint()
+        if self._ctx_dirty or fp != self._fingerprint:
             self._ctx.load_state_dict(self.state_dict())
             self._ctx.set_options(self._options)
             self._ctx_dirty = False
+            self._fingerprint = fp
+            self._weights_gen += 1
         return self._ctx
 
     def _workspace(self, ctx, device, b, h, w, prec, u8=False):
-        key = (device, b, h, w, prec, u8)
-        if self._ws_key != key:
+        """One scratch block, kept at the largest size any call has needed (a smaller batch or the
+        ragged last chunk of a video reuses it instead of freeing and reallocating gigabytes)."""
+        nbytes = ctx.workspace_bytes(b, h, w, prec, u8)
+        if self._ws is None or self._ws.device != device or self._ws.numel() < nbytes:
             self._ws = None  # release before allocating the next one
-            nbytes = ctx.workspace_bytes(b, h, w, prec, u8)
             self._ws = torch.empty(nbytes, dtype=torch.uint8, device=device)
-            self._ws_key = key
         return self._ws
 
     def _check_pair(self, frame1, frame2, dtype_ok):
@@ -221,7 +294,8 @@ class FrameInterpolationUNet(nn.Module):
         """Parity-test hook: run one forward keeping every stage and return
         ({tap name: fp32 NCHW tensor}, output)."""
         saved = self._options
-        self.set_options(unfused=bool(saved & _native.OPT_UNFUSED), keep_all=True)
+        self.set_options(unfused=bool(saved & _native.OPT_UNFUSED), keep_all=True,
+                         legacy_tiles=bool(saved & _native.OPT_LEGACY_TILES))
         try:
             out = self.forward(frame1, frame2)
             b, _, h, w = frame1.shape
@@ -240,7 +314,14 @@ class GraphedForward:
     the ~20-25 kernel launches of a forward replay as one graph launch, which matters for the
     reference's own workload (a single 256x256 pair is launch-bound).  `fiunet_forward` neither
     allocates nor synchronises, so it captures as is.  Call with tensors of the captured shape;
-    the returned tensor is the graph's static output buffer (clone it to keep it)."""
+    the returned tensor is the graph's static output buffer (clone it to keep it).
+
+    The graph holds raw device pointers, so this object OWNS every buffer it captured: its own
+    input/output tensors and its own workspace (never the model's cached one, which a later eager
+    call of another shape may free).  The prepared weights belong to the model's HIP context and are
+    re-uploaded (freed + reallocated) whenever the parameters change; `__call__` compares the
+    model's upload generation, precision and context with the ones captured and transparently
+    re-captures when they differ, so a replay never reads freed memory."""
 
     def __init__(self, model: "FrameInterpolationUNet", batch: int, height: int, width: int):
         dev = next(model.parameters()).device
@@ -250,17 +331,41 @@ class GraphedForward:
         self.model = model
         self.f1 = torch.zeros(batch, c, height, width, device=dev)
         self.f2 = torch.zeros(batch, c, height, width, device=dev)
+        self.out = torch.empty_like(self.f1)
+        self.ws = None
+        self.captures = 0
+        self._capture()
+
+    def _capture(self):
+        model, dev = self.model, self.f1.device
+        model._check_pair(self.f1, self.f2, (torch.float32,))
+        b, _, h, w = self.f1.shape
+        ctx = model._context(dev)              # uploads the weights if they are stale
+        prec = _PRECISIONS[model.precision]
+        nbytes = ctx.workspace_bytes(b, h, w, prec)
+        if self.ws is None or self.ws.numel() < nbytes:
+            self.ws = None
+            self.ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+        self._ctx, self._gen, self._prec = ctx, model._weights_gen, model.precision
         side = torch.cuda.Stream(device=dev)
         side.wait_stream(torch.cuda.current_stream(dev))
-        with torch.cuda.stream(side):  # warm-up: weight upload, workspace, LDS attributes
+        with torch.cuda.stream(side), torch.cuda.device(dev):  # warm-up: LDS attributes, lazy init
             for _ in range(2):
-                model(self.f1, self.f2)
+                ctx.forward(self.f1, self.f2, self.out, prec, self.ws)
         torch.cuda.current_stream(dev).wait_stream(side)
         self.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph):
-            self.out = model(self.f1, self.f2)
+        with torch.cuda.device(dev), torch.cuda.graph(self.graph):
+            ctx.forward(self.f1, self.f2, self.out, prec, self.ws)
+        self.captures += 1
+
+    def _stale(self) -> bool:
+        m = self.model
+        return (m._ctx is not self._ctx or m._ctx_dirty or m.precision != self._prec
+                or m._weights_gen != self._gen or m._current_fingerprint() != m._fingerprint)
 
     def __call__(self, frame1: torch.Tensor, frame2: torch.Tensor) -> torch.Tensor:
+        if self._stale():
+            self._capture()
         self.f1.copy_(frame1)
         self.f2.copy_(frame2)
         self.graph.replay()

@@ -43,8 +43,10 @@ enum fiunet_precision { FIUNET_FP32 = 0, FIUNET_BF16 = 1 };
 enum fiunet_option {
     FIUNET_OPT_UNFUSED = 1, /* ablation: run max-pool, upsample+pad+concat and the 1x1 head as
                                separate kernels instead of fusing them into the consumer conv */
-    FIUNET_OPT_KEEP_ALL = 2 /* also store the last 64-ch activation (tap 17) that the fused 1x1
+    FIUNET_OPT_KEEP_ALL = 2,/* also store the last 64-ch activation (tap 17) that the fused 1x1
                                head otherwise keeps in registers; for fiunet_debug_read_activation */
+    FIUNET_OPT_LEGACY_TILES = 4 /* A/B runs: keep every conv on the two-workgroups-per-CU kernel
+                               (conv3x3_mfma_kernel) instead of the 8-wave tile-pair kernel; same bits */
 };
 
 typedef struct fiunet_ctx fiunet_ctx;
@@ -68,7 +70,11 @@ int fiunet_set_options(fiunet_ctx* ctx, unsigned flags);
 int fiunet_load_weights(fiunet_ctx* ctx, int n, const char* const* names,
                         const float* const* host_ptrs, const int64_t* numels);
 
-/* Bytes of device scratch fiunet_forward needs for a [B,*,H,W] batch; 0 on bad arguments. */
+/* Bytes of device scratch fiunet_forward needs for a [B,*,H,W] batch; 0 on bad arguments.
+ * Activations whose lifetimes do not overlap share bytes (the reference, under no_grad, frees every
+ * non-skip tensor as it goes: model/unet.py:84-95), so the figure depends on the options in force
+ * (FIUNET_OPT_KEEP_ALL pins all 18 activations, FIUNET_OPT_UNFUSED adds the concat scratch): query it
+ * AFTER fiunet_set_options.  B=8 1080x1920: 5.9 GB bf16 / 11.8 GB fp32. */
 size_t fiunet_workspace_bytes(const fiunet_ctx* ctx, int B, int H, int W, int precision);
 
 /* Replaces FrameInterpolationUNet.forward(frame1, frame2) in eval mode

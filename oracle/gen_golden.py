@@ -36,6 +36,15 @@ def strided_sample(t: torch.Tensor, n: int = 2048):
 RGB_WEIGHT_SEED = 77
 
 
+def write_module_tree(model):
+    """Attribute tree of the reference module (callers reach into
+    `model.unet.inc.double_conv[0]`, `down1.maxpool_conv[1]`, `up1.up`): one line per
+    named_modules() entry with the class name and the number of direct children."""
+    with open(os.path.join(GOLD, "named_modules.txt"), "w") as f:
+        for name, mod in model.named_modules():
+            f.write(f"{name}\t{type(mod).__name__}\t{len(list(mod.children()))}\n")
+
+
 def gen_rgb():
     """RGB 6->3 variant: the reference's own parametric
     `UNet(n_channels=6, n_classes=3, bilinear=True)` (unet.py:66) on cat([frame1, frame2]) -- the
@@ -66,6 +75,10 @@ def main():
     if "--rgb-only" in sys.argv:  # add the RGB fixtures without re-recording the others
         os.makedirs(GOLD, exist_ok=True)
         return gen_rgb()
+    if "--modules-only" in sys.argv:
+        sys.path.insert(0, REF_DIR)
+        from unet import FrameInterpolationUNet
+        return write_module_tree(FrameInterpolationUNet(bilinear=True))
     sys.path.insert(0, REF_DIR)
     from unet import FrameInterpolationUNet  # the reference class (unet.py:97)
 
@@ -86,6 +99,7 @@ def main():
             f.write(f"{k}\t{','.join(map(str, shp))}\t{dt}\n")
     nparams = sum(p.numel() for p in model.parameters())
     print("params:", nparams)
+    write_module_tree(model)
 
     # ---- whole-net outputs, stored in full (small sizes) --------------------------------
     full_cases = [  # name, seed, B, H, W

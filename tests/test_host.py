@@ -112,3 +112,38 @@ def test_partition_pairs():
             parts = video.partition_pairs(n, w)
             covered = [i for s, c in parts for i in range(s, s + c)]
             assert covered == list(range(n - 1))
+
+
+def test_module_tree_matches_reference(golden_dir):
+    """named_modules() names, child counts and nn.Sequential-style indexing equal the reference's
+    (tests/golden/named_modules.txt, dumped from /root/reference/model/unet.py by gen_golden.py)."""
+    ref = [l.rstrip("\n").split("\t") for l in open(os.path.join(golden_dir, "named_modules.txt"))]
+    m = P.FrameInterpolationUNet(bilinear=True)
+    mine = {n: mod for n, mod in m.named_modules()}
+    assert [n for n, _ in m.named_modules()] == [r[0] for r in ref]
+    for name, cls, nchild in ref:
+        assert len(list(mine[name].children())) == int(nchild), name
+        if cls in ("Conv2d", "BatchNorm2d"):
+            assert type(mine[name]).__name__ == cls, name
+    dc = m.unet.inc.double_conv
+    assert len(dc) == 6 and dc[0] is dc["0"] and dc[-2] is dc["4"] and len(dc[:2]) == 2
+    assert isinstance(dc[0], torch.nn.Conv2d) and isinstance(dc[4], torch.nn.BatchNorm2d)
+    assert m.unet.down1.maxpool_conv[1].double_conv[3].weight.shape == (128, 128, 3, 3)
+    assert m.unet.up1.conv.double_conv[0].weight.shape == (512, 1024, 3, 3)
+    assert hasattr(m.unet.up1, "up") and [type(x).__name__ for x in dc][0] == "Conv2d"
+    with pytest.raises(IndexError):
+        dc[6]
+
+
+def test_module_copies_and_pickles_without_the_hip_context(seeded_sd):
+    import copy, io
+    m = P.FrameInterpolationUNet(bilinear=True)
+    m.load_state_dict(seeded_sd)
+    m._ctx = object()  # stands in for a live ctypes handle (not picklable in the real case either)
+    m2 = copy.deepcopy(m)
+    assert m2._ctx is None and m2._ctx_dirty
+    buf = io.BytesIO()
+    torch.save(m, buf)
+    buf.seek(0)
+    m3 = torch.load(buf, weights_only=False)
+    assert m3._ctx is None and torch.equal(m3.state_dict()["unet.outc.conv.bias"], seeded_sd["unet.outc.conv.bias"])
