@@ -392,7 +392,11 @@ template <int BN, int TH, int TW, int MODE> struct ConvTile {
     static constexpr int PATCH_OFF = IN_BYTES + 2 * W_BYTES + SPARE_BYTES;
     // two bf16 images (hi, lo) of [PATCH_H][PATCH_W][2 frames] + 64 B of zero pad each
     static constexpr int PATCH_BYTES = MODE == SRC_STEM ? 2 * (PATCH_H * PATCH_W * 4 + 64) : 0;
-    static constexpr int LDS_BYTES = PATCH_OFF + ((PATCH_BYTES + 255) / 256) * 256;
+    // CONCAT_UP: the bilinear mapping of this tile, one 16-B entry per in-tile row and per in-tile
+    // pixel column (same for every plane, so it is evaluated once per tile, not per plane)
+    static constexpr int TAB_OFF = PATCH_OFF + ((PATCH_BYTES + 255) / 256) * 256;
+    static constexpr int TAB_BYTES = MODE == SRC_CONCAT_UP ? ((THP + TW + 2) * 16 + 255) / 256 * 256 : 0;
+    static constexpr int LDS_BYTES = TAB_OFF + TAB_BYTES;
     static_assert(LDS_BYTES <= 80 * 1024, "two workgroups must fit in the CU's 160 KiB of LDS");
 };
 
@@ -724,15 +728,45 @@ __global__ __launch_bounds__(256, conv_occupancy(BN, TH, TW)) void conv3x3_mfma_
     //      pixels of this plane) is DMA-ed into the idle weight slot + spare region, then every
     //      thread interpolates its chunks LDS -> LDS: one memory round trip per plane instead of
     //      one per batch of register loads, and no VGPRs held across it. ---------------------------
-    // (pixel column, chunk) pairs of one in-tile row, and the number of row segments a column is
-    // cut into so that the tasks fill the 256 threads: cost ~ passes * (rows per segment + 1)
+    // Work split of the interpolation.  A column = (in-tile pixel column, 16-B chunk); a wave walks
+    // DOWN 64 columns at once, all lanes on the same row, so the row mapping is wave-uniform (scalar
+    // branches) and the horizontally interpolated low-res rows are reused from one output row to the
+    // next.  The (TW+2)*4 columns are cut into groups of 64 ("main" groups, NMAIN of them) whose rows
+    // are shared out over 4/NMAIN waves each, plus a tail of NTC < 64 columns whose NTC*THP elements
+    // are interpolated independently, a quarter per wave: all four waves get the same amount of work
+    // (the round-1 split left waves 2-3 idle and gave waves 0-1 every row).
     constexpr int UP_NCOL = (TW + 2) * 4;
-    constexpr int UP_NSEG = up_segments(THP, UP_NCOL);
-    constexpr int UP_SEGR = (THP + UP_NSEG - 1) / UP_NSEG;
+    constexpr int UP_NMAIN = UP_NCOL / 64;            // 2 (TW = 32) or 1 (TW = 16)
+    constexpr int UP_NTC = UP_NCOL - UP_NMAIN * 64;   // 8 tail columns
+    constexpr int UP_WPG = 4 / UP_NMAIN;              // waves per main group
+    constexpr int UP_SEGR = (THP + UP_WPG - 1) / UP_WPG;
+    constexpr int UP_NTAIL = UP_NTC * THP;            // tail elements
+    constexpr int UP_TAILW = (UP_NTAIL + 3) / 4;      // ... per wave
+    static_assert(MODE != SRC_CONCAT_UP || (UP_NMAIN >= 1 && UP_NMAIN <= 2), "interpolation work split");
     int lr_y = 0, lr_x = 0;  // low-res origin of this tile's staging window
-    if (MODE == SRC_CONCAT_UP) {
+    char* const ytab = smem + Tile::TAB_OFF;          // [THP]   {off0, off1 (bytes into staging; < 0: zero row), hy, ly}
+    char* const xtab = ytab + THP * 16;               // [TW+2]  {s0, s1 (bytes; < 0: zero column), hx, lx}
+    if constexpr (MODE == SRC_CONCAT_UP) {
         const UpCoord u = up_coord(a, y0 - 1, x0 - 1);
         lr_y = u.y0; lr_x = u.x0;
+        // the mapping of in-tile row py / column px, evaluated ONCE per tile (it is the same for
+        // every plane); published by the barrier that ends the prologue
+        if (tid < THP) {
+            const int y = y0 - 1 + tid;
+            const UpAxis uy = up_axis_y(a, min(max(y, 0), a.H - 1));
+            const bool ok = uy.ok & (y >= 0) & (y < a.H);
+            *reinterpret_cast<uint4*>(ytab + tid * 16) =
+                make_uint4(ok ? (unsigned)((uy.i0 - lr_y) * (Tile::LRP * 64)) : 0x80000000u,
+                           (unsigned)((uy.i1 - lr_y) * (Tile::LRP * 64)), __float_as_uint(uy.h),
+                           __float_as_uint(uy.l));
+        } else if (tid >= 64 && tid < 64 + TW + 2) {
+            const int px = tid - 64, x = x0 - 1 + px;
+            const UpAxis ux = up_axis_x(a, min(max(x, 0), a.W - 1));
+            const bool ok = ux.ok & (x >= 0) & (x < a.W);
+            *reinterpret_cast<uint4*>(xtab + px * 16) =
+                make_uint4(ok ? (unsigned)((ux.i0 - lr_x) * 64) : 0x80000000u, (unsigned)((ux.i1 - lr_x) * 64),
+                           __float_as_uint(ux.h), __float_as_uint(ux.l));
+        }
     }
     auto gather_plane_up = [&](int plane, int idle_slot) __attribute__((always_inline)) {
         constexpr int LRP = Tile::LRP, LRH = Tile::LRH;
@@ -754,53 +788,71 @@ __global__ __launch_bounds__(256, conv_occupancy(BN, TH, TW)) void conv3x3_mfma_
         __syncthreads();
         STAMP_UP(6);
         const char* const stg = lds_w + stg_off;
-        // Column walk: a task is one (pixel column, 16-B chunk) of the in-tile over a segment of
-        // rows.  Going down the column, consecutive output rows share their low-res source rows
-        // (scale < 1/2), so the horizontal interpolation of a low-res row is computed once and
-        // kept in registers; an output row then costs one vertical lerp.  Same arithmetic as
-        // chunk_bilerp, ~3x fewer instructions than interpolating every output independently.
         constexpr int NE = Elem<T>::NE;
-        for (int tsk = tid; tsk < UP_NSEG * UP_NCOL; tsk += 256) {
-            const int seg = UP_NSEG == 1 ? 0 : tsk / UP_NCOL, col = tsk - seg * UP_NCOL;
-            const int px = col >> 2, ch = col & 3;
-            const int x = x0 - 1 + px;
-            const UpAxis ux = up_axis_x(a, min(max(x, 0), aW - 1));
-            const bool okx = ux.ok & (x >= 0) & (x < aW);
-            const char* const s0 = stg + (ux.i0 - lr_x) * 64 + ch * 16;
-            const char* const s1 = stg + (ux.i1 - lr_x) * 64 + ch * 16;
+        // ---- main groups: column walk over this wave's row segment ------------------------------
+        {
+            const int grp = UP_NMAIN == 1 ? 0 : (wave & 1), seg = UP_NMAIN == 1 ? wave : (wave >> 1);
+            const int col = grp * 64 + lane, px = col >> 2, ch = col & 3;
+            const uint4 xt = *reinterpret_cast<const uint4*>(xtab + px * 16);
+            const bool okx = (int)xt.x >= 0;
+            const char* const s0 = stg + (okx ? (int)xt.x : 0) + ch * 16;
+            const char* const s1 = stg + (okx ? (int)xt.y : 0) + ch * 16;
+            const float hx = __uint_as_float(xt.z), lx = __uint_as_float(xt.w);
             float h0[NE], h1[NE];
-            int cy0 = -1, cy1 = -1;  // low-res rows currently held in h0 / h1
 #pragma unroll
             for (int i = 0; i < NE; ++i) h0[i] = h1[i] = 0.f;
-            const int pend_row = min(THP, (seg + 1) * UP_SEGR);
+            int c0 = -1, c1 = -1;  // staging row offsets currently held in h0 / h1 (wave-uniform)
+            const int rbeg = seg * UP_SEGR, rend = min(THP, rbeg + UP_SEGR);
 #pragma unroll 1
-            for (int py = seg * UP_SEGR; py < pend_row; ++py) {
-                const int y = y0 - 1 + py;
-                const UpAxis uy = up_axis_y(a, min(max(y, 0), aH - 1));
-                const bool ok = okx & uy.ok & (y >= 0) & (y < aH);
-                if (uy.i0 != cy0) {
-                    if (uy.i0 == cy1) {
+            for (int py = rbeg; py < rend; ++py) {
+                const uint4 yt = *reinterpret_cast<const uint4*>(ytab + py * 16);  // same address in every lane
+                const int o0 = __builtin_amdgcn_readfirstlane((int)yt.x);
+                const int o1 = __builtin_amdgcn_readfirstlane((int)yt.y);
+                uint4 v = make_uint4(0u, 0u, 0u, 0u);
+                if (o0 >= 0) {  // rows outside the image / the upsampled extent stay zero (conv pad, F.pad)
+                    if (o0 != c0) {
+                        if (o0 == c1) {
 #pragma unroll
-                        for (int i = 0; i < NE; ++i) h0[i] = h1[i];
-                    } else {
-                        const int r = (uy.i0 - lr_y) * (LRP * 64);
-                        chunk_hlerp<T>(*reinterpret_cast<const uint4*>(s0 + r),
-                                       *reinterpret_cast<const uint4*>(s1 + r), ux.h, ux.l, h0);
+                            for (int i = 0; i < NE; ++i) h0[i] = h1[i];
+                        } else {
+                            chunk_hlerp<T>(*reinterpret_cast<const uint4*>(s0 + o0),
+                                           *reinterpret_cast<const uint4*>(s1 + o0), hx, lx, h0);
+                        }
+                        c0 = o0;
                     }
-                    cy0 = uy.i0;
-                }
-                if (uy.i1 != cy1) {
-                    if (uy.i1 == cy0) {
+                    if (o1 != c1) {
+                        if (o1 == c0) {
 #pragma unroll
-                        for (int i = 0; i < NE; ++i) h1[i] = h0[i];
-                    } else {
-                        const int r = (uy.i1 - lr_y) * (LRP * 64);
-                        chunk_hlerp<T>(*reinterpret_cast<const uint4*>(s0 + r),
-                                       *reinterpret_cast<const uint4*>(s1 + r), ux.h, ux.l, h1);
+                            for (int i = 0; i < NE; ++i) h1[i] = h0[i];
+                        } else {
+                            chunk_hlerp<T>(*reinterpret_cast<const uint4*>(s0 + o1),
+                                           *reinterpret_cast<const uint4*>(s1 + o1), hx, lx, h1);
+                        }
+                        c1 = o1;
                     }
-                    cy1 = uy.i1;
+                    v = chunk_vlerp<T>(h0, h1, __uint_as_float(yt.z), __uint_as_float(yt.w));
+                    if (!okx) v = make_uint4(0u, 0u, 0u, 0u);
                 }
-                uint4 v = chunk_vlerp<T>(h0, h1, uy.h, uy.l);
+                const int row = py * TWP + px;
+                *reinterpret_cast<uint4*>(lds_in + row * 64 + ((ch ^ swz(row)) << 4)) = v;
+            }
+        }
+        // ---- tail columns: UP_NTC x THP elements, a quarter per wave, each interpolated on its own
+        //      (chunk_bilerp = chunk_hlerp + chunk_vlerp operation for operation: the same bits)
+        for (int k = lane; k < UP_TAILW; k += 64) {
+            const int e = wave * UP_TAILW + k;
+            if (e < UP_NTAIL) {
+                const int py = e / UP_NTC, col = UP_NMAIN * 64 + (e - py * UP_NTC), px = col >> 2, ch = col & 3;
+                const uint4 xt = *reinterpret_cast<const uint4*>(xtab + px * 16);
+                const uint4 yt = *reinterpret_cast<const uint4*>(ytab + py * 16);
+                const bool ok = ((int)xt.x >= 0) & ((int)yt.x >= 0);
+                const char* const q0 = stg + (ok ? (int)xt.x : 0) + ch * 16;
+                const char* const q1 = stg + (ok ? (int)xt.y : 0) + ch * 16;
+                const int o0 = ok ? (int)yt.x : 0, o1 = ok ? (int)yt.y : 0;
+                uint4 v = chunk_bilerp<T>(*reinterpret_cast<const uint4*>(q0 + o0), *reinterpret_cast<const uint4*>(q1 + o0),
+                                          *reinterpret_cast<const uint4*>(q0 + o1), *reinterpret_cast<const uint4*>(q1 + o1),
+                                          __uint_as_float(xt.z), __uint_as_float(xt.w), __uint_as_float(yt.z),
+                                          __uint_as_float(yt.w));
                 if (!ok) v = make_uint4(0u, 0u, 0u, 0u);
                 const int row = py * TWP + px;
                 *reinterpret_cast<uint4*>(lds_in + row * 64 + ((ch ^ swz(row)) << 4)) = v;
