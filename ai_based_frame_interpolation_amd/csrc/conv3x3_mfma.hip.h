@@ -88,7 +88,7 @@ struct ConvArgs {
     // slice s stores its raw fp32 partial sums to kslab[s][B*H*W][Cout]; splitk_finalize_kernel adds
     // the slices in order (deterministic) and applies scale/shift/ReLU.
     int ksplit;
-    int legacy;          // host side only: keep to conv3x3_mfma_kernel (FIUNET_OPT_LEGACY_TILES, A/B runs)
+    int pair;            // host side only: 8-wave tile-pair kernel where it applies (FIUNET_OPT_PAIR_TILES)
     float* kslab;
     unsigned long long* stamp;  // diagnostic builds (-DFIUNET_STAMP) only: 8 cycle sums per wave
     const float* head_w; // fused 1x1 head: [head_nc][64]
@@ -670,10 +670,10 @@ __global__ __launch_bounds__(256, conv_occupancy(BN, TH, TW)) void conv3x3_mfma_
     const char* const zero_page = (const char*)a.zero_page;
     // The per-lane source offset of every piece is plane-invariant in the blocked layout.  Where
     // registers allow (direct kernels without the fused head) it is computed once (NPW registers)
-    // and a plane's gather costs ~10 instructions per piece; the concat / head variants, which
-    // are at the 256-VGPR limit, recompute it per plane instead (hoisting there spilled and
-    // measured slower).
-    constexpr bool HOIST = (MODE == SRC_DIRECT && HNC == 0);
+    // and a plane's gather costs ~10 instructions per piece; the concat / head variants and the
+    // 64-cout pooled / 32-row tiles (12-14 pieces per wave), which are at the 256-VGPR limit,
+    // recompute it per plane instead (hoisting there spilled, and measured slower).
+    constexpr bool HOIST = (MODE == SRC_DIRECT && HNC == 0 && !(BN == 64 && (EPI == EPI_POOL || TH == 32)));
     constexpr int NPW = (NPIECE + 3) / 4;
     auto piece_off = [&](int j, int opq) __attribute__((always_inline)) {
         const int row = j * 16 + (lane >> 2) + opq;

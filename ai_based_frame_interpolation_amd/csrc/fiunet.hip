@@ -103,8 +103,8 @@ struct Plan {
 // has run (model/unet.py:84-95 keeps only x1..x4 alive); here the same liveness is turned into a
 // static layout: every buffer gets the interval [stage that writes it, last stage that reads it]
 // (stage i = conv i of the 18) and buffers whose intervals do not overlap share bytes (first-fit
-// over the buffers in order of their first stage).  B=8 1080p bf16 needs 5.9 GB this way instead of
-// the 14.6 GB of one private buffer per tensor.  `keep_all` (FIUNET_OPT_KEEP_ALL, the debug
+// over the buffers in order of their first stage).  B=8 1080p bf16 needs 6.4 GB this way instead of
+// the 16.2 GB of one private buffer per tensor.  `keep_all` (FIUNET_OPT_KEEP_ALL, the debug
 // read-back) pins every activation to the end; `unfused` adds the ablation path's concat scratch;
 // the fused stem / fused head leave activations 0 / 17 out altogether.
 struct PlanOpts {
@@ -276,7 +276,6 @@ int launch_pair_cfg(ConvArgs a, hipStream_t s)
 // pair kernel: direct sources, plain / pooled epilogue, enough tile pairs to fill the 256 CUs
 template <typename T, int BN, int TH, int TW, int MODE, int EPI>
 constexpr bool pair_capable() { return MODE == SRC_DIRECT && (EPI == EPI_PLAIN || EPI == EPI_POOL) && BN == 128; }
-
 inline unsigned grid_for(size_t n);
 
 // Small problems (fewer workgroups than half the CUs, e.g. the deep levels of a single 256x256 pair,
@@ -311,7 +310,7 @@ int launch_conv_maybe_split(ConvArgs a, hipStream_t s)
     }
     if constexpr (pair_capable<T, BN, TH, TW, MODE, EPI>()) {
         const long long ntiles = (long long)a.B * ((a.W + TW - 1) / TW) * ((a.H + TH - 1) / TH);
-        if (!a.legacy && (ntiles + 1) / 2 * (a.Cout / BN) >= 256)
+        if (a.pair && (ntiles + 1) / 2 * (a.Cout / BN) >= 256)
             return launch_pair_cfg<T, BN, TH, TW, EPI>(a, s);
     }
     return launch_conv_cfg<T, BN, TH, TW, MODE, EPI>(a, s);
@@ -445,7 +444,7 @@ int forward_impl(fiunet_ctx* ctx, const float* f1, const float* f2, float* out, 
         a.relu = 1;
         a.zero_page = ctx->zero_page;
         a.ksplit = 1;
-        a.legacy = (ctx->flags & FIUNET_OPT_LEGACY_TILES) ? 1 : 0;
+        a.pair = (ctx->flags & FIUNET_OPT_PAIR_TILES) ? 1 : 0;
         // the last conv is never K-split: its fused-head form cannot be, and the ablation path must
         // accumulate in the same order to stay bit-identical with it
         a.kslab = i == NCONV - 1 ? nullptr : (float*)(ws + p.slab_off);

@@ -45,8 +45,8 @@ enum fiunet_option {
                                separate kernels instead of fusing them into the consumer conv */
     FIUNET_OPT_KEEP_ALL = 2,/* also store the last 64-ch activation (tap 17) that the fused 1x1
                                head otherwise keeps in registers; for fiunet_debug_read_activation */
-    FIUNET_OPT_LEGACY_TILES = 4 /* A/B runs: keep every conv on the two-workgroups-per-CU kernel
-                               (conv3x3_mfma_kernel) instead of the 8-wave tile-pair kernel; same bits */
+    FIUNET_OPT_PAIR_TILES = 8  /* A/B runs: direct >=128-channel convs on the 8-wave tile-pair kernel
+                               (conv3x3_pair.hip.h: shared weight ring, double-buffered in-tile); same bits */
 };
 
 typedef struct fiunet_ctx fiunet_ctx;
@@ -74,7 +74,7 @@ int fiunet_load_weights(fiunet_ctx* ctx, int n, const char* const* names,
  * Activations whose lifetimes do not overlap share bytes (the reference, under no_grad, frees every
  * non-skip tensor as it goes: model/unet.py:84-95), so the figure depends on the options in force
  * (FIUNET_OPT_KEEP_ALL pins all 18 activations, FIUNET_OPT_UNFUSED adds the concat scratch): query it
- * AFTER fiunet_set_options.  B=8 1080x1920: 5.9 GB bf16 / 11.8 GB fp32. */
+ * AFTER fiunet_set_options.  B=8 1080x1920: 6.4 GB bf16 / 12.8 GB fp32. */
 size_t fiunet_workspace_bytes(const fiunet_ctx* ctx, int B, int H, int W, int precision);
 
 /* Replaces FrameInterpolationUNet.forward(frame1, frame2) in eval mode

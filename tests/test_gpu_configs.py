@@ -192,18 +192,18 @@ def test_bf16_error_contract_on_bench_network(dev):
 
 
 @pytest.mark.parametrize("prec", ["bf16", "fp32"])
-def test_tile_pair_kernel_equals_two_workgroup_kernel_bitwise(model, dev, prec):
-    """conv3x3_pair_kernel (8 waves, two pixel tiles, shared weight ring, double-buffered in-tile)
-    sums in the same order as conv3x3_mfma_kernel: every stage and the output are bit-identical.
-    B=8 270x480 puts levels 1-2 on the pair kernel and leaves the small deep levels on the old one;
-    an odd tile count (B=3) exercises the idle second group of the last workgroup."""
+def test_tile_pair_kernel_is_bit_identical(model, dev, prec):
+    """conv3x3_pair_kernel (8 waves on two pixel tiles, shared weight ring, double-buffered in-tile;
+    FIUNET_OPT_PAIR_TILES) sums in the same order as conv3x3_mfma_kernel: every stage and the output
+    are bit-identical.  B=8 270x480 puts levels 1-2 on the pair kernel; an odd tile count (B=3)
+    exercises the idle second group of its last workgroup."""
     model.precision = prec
     for b, h, w in ((8, 270, 480), (3, 264, 480)):
         f1, f2 = O.make_frames(60 + b, b, h, w)
         f1, f2 = f1.to(dev), f2.to(dev)
-        model.set_options(legacy_tiles=True)
+        model.set_options()
         acts_a, a = model.debug_activations(f1, f2)
-        model.set_options(legacy_tiles=False)
+        model.set_options(pair_tiles=True)
         acts_b, bb = model.debug_activations(f1, f2)
         for k in acts_a:
             assert torch.equal(acts_a[k], acts_b[k]), (prec, b, k)

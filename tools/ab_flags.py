@@ -14,7 +14,7 @@ m = bench.make_bench_model(a.precision).to(dev).eval()
 gen = torch.Generator(device=dev).manual_seed(1)
 f1 = torch.rand(a.batch, 1, a.height, a.width, device=dev, generator=gen) * 2 - 1
 f2 = torch.rand(a.batch, 1, a.height, a.width, device=dev, generator=gen) * 2 - 1
-arms = {"legacy": dict(legacy_tiles=True), "new": dict(legacy_tiles=False)}
+arms = {"legacy": dict(), "new": dict(pair_tiles=True)}
 fps = {k: [] for k in arms}; stages = {k: None for k in arms}
 for k, opt in arms.items():
     m.set_options(**opt)
