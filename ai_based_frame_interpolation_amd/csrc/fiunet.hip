@@ -278,7 +278,7 @@ template <typename T, int BN, int TH, int TW, int MODE, int EPI>
 constexpr bool pair_capable() { return MODE == SRC_DIRECT && (EPI == EPI_PLAIN || EPI == EPI_POOL) && BN == 128; }
 inline unsigned grid_for(size_t n);
 
-// Small problems (fewer workgroups than half the CUs, e.g. the deep levels of a single 256x256 pair,
+// Small problems (fewer workgroups than CUs, e.g. the deep levels of a single 256x256 pair,
 // which is the only size the reference ever runs): cut the K loop over `ksplit` workgroups, then
 // reduce + scale/shift/ReLU (+ pool) in a finalize pass.  Deterministic (slices added in order).
 template <typename T, int BN, int TH, int TW, int MODE, int EPI>
@@ -289,7 +289,7 @@ int launch_conv_maybe_split(ConvArgs a, hipStream_t s)
         const int nplanes = (a.C0 + a.C1) / Elem<T>::PL;
         int ksplit = (int)std::min<long long>(std::min(nplanes / 2, 16), (256 + nblk - 1) / nblk);
         while (ksplit > 1 && (size_t)ksplit * a.B * a.H * a.W * a.Cout * 4 > kSlabBytes) --ksplit;
-        if (nblk < 128 && ksplit > 1 && a.kslab && a.dst) {
+        if (nblk < 256 && ksplit > 1 && a.kslab && a.dst) {  // fewer workgroups than CUs: cut K as well
             ConvArgs k = a;
             k.ksplit = ksplit;
             int rc = launch_conv_cfg<T, BN, TH, TW, MODE, EPI_SPLITK>(k, s);

@@ -1,6 +1,6 @@
 """Summarise rocprofv3 PMC passes of `bench.py` into profiles/pmc_summary.json + a text table.
 
-usage: python tools/pmc_summary.py gpurun_out/pmc profiles/r01_pmc
+usage: python tools/pmc_summary.py gpurun_out/prof_default profiles/r02_pmc [forwards] [commit] [--no-summary-json]
 Each pass directory holds one *_counter_collection.csv (one row per dispatch and counter).
 Corrections per /opt/skills/guides/MI355X_MICROARCH.md (HBM / rocprofv3): FETCH_SIZE and
 WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE counts 128-B requests as 64 B for wide coalesced
@@ -12,6 +12,8 @@ from collections import defaultdict
 
 src, out = sys.argv[1], sys.argv[2]
 NFW = int(sys.argv[3]) if len(sys.argv) > 3 else 4  # forwards in the profiled bench run
+COMMIT = sys.argv[4] if len(sys.argv) > 4 and not sys.argv[4].startswith("--") else "?"
+WRITE_SUMMARY = "--no-summary-json" not in sys.argv
 
 def load(pass_name):
     files = glob.glob(os.path.join(src, pass_name, "*", "*_counter_collection.csv"))
@@ -33,7 +35,11 @@ def load(pass_name):
 
 def short(n):
     """same spelling as bench.py's roofline.kernel (fiunet_profile_read names)"""
-    m = re.search(r"conv3x3_(first|mfma)_kernelI(DF16b|f)((?:Li\d+E)+)", n)
+    m = re.search(r"conv3x3_(first|mfma|pair)_kernelI(DF16b|f)((?:Li\d+E)+)", n)
+    d = re.search(r"conv3x3_(first|mfma|pair)_kernel<(float|__bf16|__hip_bfloat16)((?:, *\d+)+)>", n)
+    if d:  # already demangled (rocprofv3 demangles the float instantiations)
+        nums = re.findall(r"\d+", d.group(3))
+        return f"conv3x3_{d.group(1)}_kernel<{'f32' if d.group(2) == 'float' else 'bf16'},{','.join(nums)}>"
     if not m:
         # rocprofv3 demangles the stem's name oddly; the bench workload is the gray bf16 network
         return "conv3x3_first_kernel<bf16,1>" if "conv3x3_first_kernel" in n else n[:40]
@@ -82,5 +88,9 @@ with open(out + "_table.txt", "w") as fh:
     tot = sum(s["hbm_bytes"] for s in stages)
     line = f"total HBM bytes per forward (B=8): {tot/1e9:.2f} GB; algorithmic fused-ideal: {8*2146.1e6*2/1e9:.2f} GB"
     print(line); fh.write(line + "\n")
-# bench.py reads profiles/pmc_summary.json for roofline.traffic
-json.dump(summary, open(os.path.join(os.path.dirname(out) or ".", "pmc_summary.json"), "w"), indent=1)
+# bench.py reads profiles/pmc_summary.json for roofline.traffic (default workload only)
+if WRITE_SUMMARY:
+    import datetime
+    summary["_meta"] = {"commit": COMMIT, "date": datetime.date.today().isoformat(),
+                        "source": os.path.basename(out) + "_stages.json"}
+    json.dump(summary, open(os.path.join(os.path.dirname(out) or ".", "pmc_summary.json"), "w"), indent=1)
