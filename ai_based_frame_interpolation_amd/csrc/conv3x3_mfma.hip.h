@@ -11,7 +11,7 @@
 // tensors is ever materialised in HBM.
 //
 // Mapping onto the hardware (one workgroup = 4 waves = 256 threads, 2 workgroups per CU):
-//   * GEMM view: D[cout][pixel] += W[cout][k] * X[k][pixel], k = (channel plane, ky, kx).
+//   * GEMM view: D[cout][pixel] += W[cout][k] * X[k][pixel], k = (channel plane, kx, ky).
 //     MFMA A operand = weights (16 couts x 8k per lane-row), B operand = pixels.  With that
 //     orientation a lane of the 16x16 accumulator holds consecutive couts of one pixel, so the
 //     epilogue stores 16 contiguous bytes per lane into the blocked activation layout
@@ -19,7 +19,10 @@
 //   * A "plane" is 64 bytes of channels per pixel (32 bf16 or 16 fp32).  The input tile
 //     (TH+2)x(TW+2) pixels of one plane is staged in LDS ONCE and reused by all 9 taps -- the
 //     shifted windows are just different LDS addresses (base + immediate offset).
-//   * Weights for (plane, ky, kx=0..2) are streamed per step: 3*BN rows of 64 B, by LDS-DMA
+//   * A step is one (plane, kx): its three taps ky = 0..2 read in-tile rows r, r+1, r+2 of the same
+//     columns, so a wave fetches each (row, 16-pixel) fragment ONCE per step and uses it for up to
+//     three taps (rolling window of ROWS_W + 2 rows): 24 instead of 36 ds_read_b128 per 96 MFMAs.
+//   * Weights for (plane, kx, ky=0..2) are streamed per step: 3*BN rows of 64 B, by LDS-DMA
 //     (global_load_lds_dwordx4, 1 KiB per wave-instruction, no VGPRs) into a 2-deep ring, one
 //     step ahead of the MFMAs, so the L2 latency of the weight stream hides under the previous
 //     step's 96 MFMAs per wave.  The next plane's input tile is gathered at the plane boundary
@@ -379,7 +382,7 @@ template <int BN, int TH, int TW, int MODE> struct ConvTile {
     static constexpr int TWP = ((TW + 2 + 7) / 8) * 8;  // in-tile row pitch, multiple of 8 pixels
     static constexpr int THP = TH + 2;
     static constexpr int IN_BYTES = THP * TWP * 64;
-    static constexpr int W_BYTES = 3 * BN * 64;          // one (plane, ky) step: 3 taps
+    static constexpr int W_BYTES = 3 * BN * 64;          // one (plane, kx) step: 3 taps
     // low-res tile of an upsampled plane: rows/cols that a (TH+2)x(TW+2) window can touch
     static constexpr int LRH = (TH + 1) / 2 + 3, LRW = (TW + 1) / 2 + 3, LRP = ((LRW + 3) / 4) * 4;
     static constexpr int LR_PIECES = (LRH * LRP + 15) / 16;
@@ -648,12 +651,12 @@ __global__ __launch_bounds__(256, conv_occupancy(BN, TH, TW)) void conv3x3_mfma_
 #pragma unroll
     for (int j = 0; j < NW; ++j) {
         const int lrow = (wave * NW + j) * 16 + (lane >> 2);
-        const int kx = lrow / BN, row = lrow - kx * BN;
-        w_src_off[j] = (kx * a.Cout + row) * 64 + (((lane & 3) ^ swz(lrow)) << 4);
+        const int tap = lrow / BN, row = lrow - tap * BN;  // tap = ky within the step
+        w_src_off[j] = (tap * a.Cout + row) * 64 + (((lane & 3) ^ swz(lrow)) << 4);
     }
     auto issue_w = [&](int step) __attribute__((always_inline)) {  // step counts from this slice's start
-        const int lp = step / 3, ky = step - lp * 3, pl = pbeg + lp;
-        const char* wsrc = wbase + ((size_t)(pl * 9 + ky * 3) * a.Cout) * 64;
+        const int lp = step / 3, kx = step - lp * 3, pl = pbeg + lp;
+        const char* wsrc = wbase + ((size_t)(pl * 9 + kx * 3) * a.Cout) * 64;  // packed [plane][kx][ky][cout]
         const unsigned dst = __builtin_amdgcn_readfirstlane(
             lds_w_addr + (unsigned)((step & 1) * Tile::W_STRIDE + wave * NW * 1024));
 #pragma unroll
@@ -670,10 +673,15 @@ __global__ __launch_bounds__(256, conv_occupancy(BN, TH, TW)) void conv3x3_mfma_
     const char* const zero_page = (const char*)a.zero_page;
     // The per-lane source offset of every piece is plane-invariant in the blocked layout.  Where
     // registers allow (direct kernels without the fused head) it is computed once (NPW registers)
-    // and a plane's gather costs ~10 instructions per piece; the concat / head variants and the
-    // 64-cout pooled / 32-row tiles (12-14 pieces per wave), which are at the 256-VGPR limit,
-    // recompute it per plane instead (hoisting there spilled, and measured slower).
-    constexpr bool HOIST = (MODE == SRC_DIRECT && HNC == 0 && !(BN == 64 && (EPI == EPI_POOL || TH == 32)));
+    // and a plane's gather costs ~10 instructions per piece; the concat / head / split-K variants
+    // and the 64-cout tiles (12-14 pieces per wave), which are at the 256-VGPR limit, recompute it
+    // per plane instead (hoisting there spilled, and measured slower).
+    constexpr bool HOIST = (MODE == SRC_DIRECT && HNC == 0 && BN == 128 && EPI != EPI_SPLITK);
+    // Rolling window of in-tile rows across the three ky taps of a step (24 instead of 36 fragment
+    // reads per step): bf16 32-wide tiles.  The fp32 instantiations (4 MFMAs per fragment pair keep
+    // more operands in flight) and the 16-wide tiles have no registers to spare for the extra row
+    // and re-read every row for every tap instead; same tap order, same sums.
+    constexpr bool ROLL = sizeof(T) == 2 && FR == 2 && EPI != EPI_SPLITK;
     constexpr int NPW = (NPIECE + 3) / 4;
     auto piece_off = [&](int j, int opq) __attribute__((always_inline)) {
         const int row = j * 16 + (lane >> 2) + opq;
@@ -975,36 +983,69 @@ __global__ __launch_bounds__(256, conv_occupancy(BN, TH, TW)) void conv3x3_mfma_
     int step = 0;
     for (int plane = pbeg; plane < pend; ++plane) {
 #pragma unroll
-        for (int ky = 0; ky < 3; ++ky, ++step) {
+        for (int kx = 0; kx < 3; ++kx, ++step) {
             // W(step) and the in-tile of `plane` are resident.  Stream W(step+1) into the other
             // ring slot (its last readers passed the barrier that ended step-1).
             if (step + 1 < nsteps) issue_w(step + 1);
             const char* wcur = lds_w + (step & 1) * Tile::W_STRIDE + a_off;
+            // this wave's in-tile rows 0 .. ROWS_W+1 at column offset kx: row i serves tap ky for the
+            // output row i - ky, so every fragment is read once and used by up to three taps
+            if constexpr (ROLL) {
+                uint4 xb[ROWS_W + 2][FR];
+                auto load_row = [&](int i) __attribute__((always_inline)) {
 #pragma unroll
-            for (int kx = 0; kx < 3; ++kx) {
-                uint4 wa[4], xb[NF];
+                    for (int f = 0; f < FR; ++f)
+                        xb[i][f] = *reinterpret_cast<const uint4*>(lds_in + b_off[kx] + (i * TWP + f * 16) * 64);
+                };
 #pragma unroll
-                for (int m = 0; m < 4; ++m)
-                    wa[m] = *reinterpret_cast<const uint4*>(wcur + (kx * BN + m * 16) * 64);
+                for (int i = 0; i < ROWS_W; ++i) load_row(i);   // rows of tap ky = 0
 #pragma unroll
-                for (int n = 0; n < NF; ++n)
-                    xb[n] = *reinterpret_cast<const uint4*>(
-                        lds_in + b_off[kx] + (((n / FR) + ky) * TWP + (n % FR) * 16) * 64);
+                for (int ky = 0; ky < 3; ++ky) {
+                    uint4 wa[4];
 #pragma unroll
-                for (int m = 0; m < 4; ++m)
+                    for (int m = 0; m < 4; ++m)
+                        wa[m] = *reinterpret_cast<const uint4*>(wcur + (ky * BN + m * 16) * 64);
+                    if (ky < 2) load_row(ROWS_W + ky);  // the one new row of the next tap (row ky dies after this one)
 #pragma unroll
-                    for (int n = 0; n < NF; ++n) {
+                    for (int m = 0; m < 4; ++m)
+#pragma unroll
+                        for (int n = 0; n < NF; ++n) {
 #ifndef FIUNET_DIAG_NO_MFMA  // timing diagnostic: memory side alone (results are garbage)
-                        mma_chunk<T>(acc[m][n], wa[m], xb[n]);
+                            mma_chunk<T>(acc[m][n], wa[m], xb[n / FR + ky][n % FR]);
 #endif
-                    }
+                        }
+                }
+            } else {
+#pragma unroll
+                for (int ky = 0; ky < 3; ++ky) {
+                    // compiler-only barrier: without it hipcc merges the fragment reads that
+                    // consecutive taps share and keeps them in registers, i.e. builds the rolling
+                    // window after all (and spills)
+                    asm volatile("" ::: "memory");
+                    uint4 wa[4], xb[NF];
+#pragma unroll
+                    for (int m = 0; m < 4; ++m)
+                        wa[m] = *reinterpret_cast<const uint4*>(wcur + (ky * BN + m * 16) * 64);
+#pragma unroll
+                    for (int n = 0; n < NF; ++n)
+                        xb[n] = *reinterpret_cast<const uint4*>(
+                            lds_in + b_off[kx] + (((n / FR) + ky) * TWP + (n % FR) * 16) * 64);
+#pragma unroll
+                    for (int m = 0; m < 4; ++m)
+#pragma unroll
+                        for (int n = 0; n < NF; ++n) {
+#ifndef FIUNET_DIAG_NO_MFMA
+                            mma_chunk<T>(acc[m][n], wa[m], xb[n]);
+#endif
+                        }
+                }
             }
 #ifdef FIUNET_STAMP
             asm volatile("" :: "v"(acc[3][NF - 1][3]));  // keep the stamp behind the last MFMA
             __builtin_amdgcn_sched_barrier(0);
 #endif
             STAMP(2);
-            if (ky == 2 && plane + 1 < pend) {
+            if (kx == 2 && plane + 1 < pend) {
                 __syncthreads();  // every wave is done with this plane's in-tile and with W(step)
                 gather_plane(plane + 1, step & 1);
                 lds_dma_wait_all();

@@ -9,13 +9,13 @@
 // Sharing the ring between the two tiles frees 48 KiB, which here buys a DOUBLE-BUFFERED input tile
 // per group:
 //     LDS = 2 groups x 2 buffers x in-tile (25.6 KiB at 8x32) + 2 x 24 KiB ring = 148 KiB.
-// The gather of plane p+1 is issued during the first (ky = 0) step of plane p into the idle buffer
+// The gather of plane p+1 is issued during the first (kx = 0) step of plane p into the idle buffer
 // and has two full steps (~6k cycles) to land; weights are streamed one step ahead as before.  The K
 // loop then has exactly one barrier per step and no gather bubble, the weight bytes a CU pulls from
 // L2 halve, and the LDS-DMA queue is drained with COUNTED waits (the in-tile pieces stay in flight
-// across the ky = 0 barrier).
+// across the kx = 0 barrier).
 //
-// Same arithmetic, same summation order (planes, ky, kx) and the same epilogue code as
+// Same arithmetic, same summation order (planes, kx, ky) and the same epilogue code as
 // conv3x3_mfma_kernel: outputs are bit-identical to it.
 //
 // Replaces the same reference ops as conv3x3_mfma.hip.h (DoubleConv: /root/reference/model/unet.py:11-18;
@@ -111,12 +111,12 @@ __global__ __launch_bounds__(512, 2) void conv3x3_pair_kernel(const ConvArgs a)
 #pragma unroll
     for (int j = 0; j < NW; ++j) {
         const int lrow = (wave8 * NW + j) * 16 + (lane >> 2);
-        const int kx = lrow / BN, row = lrow - kx * BN;
-        w_src_off[j] = (kx * a.Cout + row) * 64 + (((lane & 3) ^ swz(lrow)) << 4);
+        const int tap = lrow / BN, row = lrow - tap * BN;  // tap = ky within the (plane, kx) step
+        w_src_off[j] = (tap * a.Cout + row) * 64 + (((lane & 3) ^ swz(lrow)) << 4);
     }
     auto issue_w = [&](int step) __attribute__((always_inline)) {
-        const int pl = step / 3, ky = step - pl * 3;
-        const char* wsrc = wbase + ((size_t)(pl * 9 + ky * 3) * a.Cout) * 64;
+        const int pl = step / 3, kx = step - pl * 3;
+        const char* wsrc = wbase + ((size_t)(pl * 9 + kx * 3) * a.Cout) * 64;  // packed [plane][kx][ky][cout]
         const unsigned dst = __builtin_amdgcn_readfirstlane(
             lds_w_addr + (unsigned)((step & 1) * Tile::W_BYTES + wave8 * NW * 1024));
 #pragma unroll
@@ -165,33 +165,61 @@ __global__ __launch_bounds__(512, 2) void conv3x3_pair_kernel(const ConvArgs a)
         const char* const in_cur = lds_in0 + par * Tile::IN_BYTES;
         const bool more = plane + 1 < nplanes;
 #pragma unroll
-        for (int ky = 0; ky < 3; ++ky, ++step) {
+        for (int kx = 0; kx < 3; ++kx, ++step) {
             // resident: W(step) and this plane's in-tile.  In flight after these issues: W(step+1)
-            // (oldest), then -- on ky = 0 -- the next plane's in-tile pieces (youngest).
+            // (oldest), then -- on kx = 0 -- the next plane's in-tile pieces (youngest).
             if (step + 1 < nsteps) issue_w(step + 1);
-            if (ky == 0 && more) gather_plane(plane + 1, par ^ 1);
+            if (kx == 0 && more) gather_plane(plane + 1, par ^ 1);
             const char* wcur = lds_w + (step & 1) * Tile::W_BYTES + a_off;
+            constexpr bool ROLL = sizeof(T) == 2 && FR == 2;  // rolling row window: see conv3x3_mfma_kernel
+            if constexpr (ROLL) {
+                uint4 xb[ROWS_W + 2][FR];
+                auto load_row = [&](int i) __attribute__((always_inline)) {
 #pragma unroll
-            for (int kx = 0; kx < 3; ++kx) {
-                uint4 wa[4], xb[NF];
+                    for (int f = 0; f < FR; ++f)
+                        xb[i][f] = *reinterpret_cast<const uint4*>(in_cur + b_off[kx] + (i * TWP + f * 16) * 64);
+                };
 #pragma unroll
-                for (int m = 0; m < 4; ++m)
-                    wa[m] = *reinterpret_cast<const uint4*>(wcur + (kx * BN + m * 16) * 64);
+                for (int i = 0; i < ROWS_W; ++i) load_row(i);
 #pragma unroll
-                for (int n = 0; n < NF; ++n)
-                    xb[n] = *reinterpret_cast<const uint4*>(
-                        in_cur + b_off[kx] + (((n / FR) + ky) * TWP + (n % FR) * 16) * 64);
+                for (int ky = 0; ky < 3; ++ky) {
+                    uint4 wa[4];
 #pragma unroll
-                for (int m = 0; m < 4; ++m)
+                    for (int m = 0; m < 4; ++m)
+                        wa[m] = *reinterpret_cast<const uint4*>(wcur + (ky * BN + m * 16) * 64);
+                    if (ky < 2) load_row(ROWS_W + ky);
 #pragma unroll
-                    for (int n = 0; n < NF; ++n) mma_chunk<T>(acc[m][n], wa[m], xb[n]);
+                    for (int m = 0; m < 4; ++m)
+#pragma unroll
+                        for (int n = 0; n < NF; ++n) mma_chunk<T>(acc[m][n], wa[m], xb[n / FR + ky][n % FR]);
+                }
+            } else {
+#pragma unroll
+                for (int ky = 0; ky < 3; ++ky) {
+                    // compiler-only barrier: without it hipcc merges the fragment reads that
+                    // consecutive taps share and keeps them in registers, i.e. builds the rolling
+                    // window after all (and spills)
+                    asm volatile("" ::: "memory");
+                    uint4 wa[4], xb[NF];
+#pragma unroll
+                    for (int m = 0; m < 4; ++m)
+                        wa[m] = *reinterpret_cast<const uint4*>(wcur + (ky * BN + m * 16) * 64);
+#pragma unroll
+                    for (int n = 0; n < NF; ++n)
+                        xb[n] = *reinterpret_cast<const uint4*>(
+                            in_cur + b_off[kx] + (((n / FR) + ky) * TWP + (n % FR) * 16) * 64);
+#pragma unroll
+                    for (int m = 0; m < 4; ++m)
+#pragma unroll
+                        for (int n = 0; n < NF; ++n) mma_chunk<T>(acc[m][n], wa[m], xb[n]);
+                }
             }
             // W(step+1) must have landed before the barrier that publishes it.  LDS-DMAs of a wave
-            // retire in issue order, so on ky = 0 it is enough to wait until at most the in-tile
+            // retire in issue order, so on kx = 0 it is enough to wait until at most the in-tile
             // pieces issued after it are outstanding (NPW_MIN: a wave that issued one piece more
             // just waits for that piece too); they are needed two barriers later and are waited
             // for by the vmcnt(0) of the next step.
-            if (ky == 0 && more) lds_dma_wait_le<NPW_MIN>();
+            if (kx == 0 && more) lds_dma_wait_le<NPW_MIN>();
             else lds_dma_wait_all();
             __builtin_amdgcn_s_barrier();
         }

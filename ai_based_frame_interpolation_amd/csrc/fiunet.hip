@@ -65,8 +65,8 @@ const int kSrc1[NCONV] = {-1, -1, -1, -1, -1, -1, -1, -1, -1, -1, 9, -1, 11, -1,
 
 struct ConvWeights {
     int cin = 0, cout = 0;
-    void* w_f32 = nullptr;   // packed [cin/16][9][cout][16] fp32   (conv 0: [9][cin][64])
-    void* w_bf16 = nullptr;  // packed [cin/32][9][cout][32] bf16
+    void* w_f32 = nullptr;   // packed [cin/16][kx][ky][cout][16] fp32   (conv 0: [9][cin][64])
+    void* w_bf16 = nullptr;  // packed [cin/32][kx][ky][cout][32] bf16
     float* scale = nullptr;
     float* shift = nullptr;
 };
@@ -289,7 +289,13 @@ int launch_conv_maybe_split(ConvArgs a, hipStream_t s)
         const int nplanes = (a.C0 + a.C1) / Elem<T>::PL;
         int ksplit = (int)std::min<long long>(std::min(nplanes / 2, 16), (256 + nblk - 1) / nblk);
         while (ksplit > 1 && (size_t)ksplit * a.B * a.H * a.W * a.Cout * 4 > kSlabBytes) --ksplit;
-        if (nblk < 256 && ksplit > 1 && a.kslab && a.dst) {  // fewer workgroups than CUs: cut K as well
+        // Fewer workgroups than CUs: cut K as well.  The cut changes the fp32 summation order, so it
+        // must not depend on the batch size for frames whose batches are compared bit for bit (a
+        // video's ragged last chunk, B=1 vs B=8 at 1080p): layers with >= 64 workgroups PER IMAGE
+        // keep round 1's rule (split below 128 workgroups in total, which such a layer never has
+        // for B >= 2); small frames, where a single pair is K-split anyway, split below 256.
+        const long long thr = nblk / a.B < 64 ? 256 : 128;
+        if (nblk < thr && ksplit > 1 && a.kslab && a.dst) {
             ConvArgs k = a;
             k.ksplit = ksplit;
             int rc = launch_conv_cfg<T, BN, TH, TW, MODE, EPI_SPLITK>(k, s);
@@ -650,9 +656,12 @@ int fiunet_load_weights(fiunet_ctx* ctx, int n, const char* const* names,
             const int co16 = bf16_row_to_cout(R);
             for (int ci = 0; ci < cin; ++ci)
                 for (int t = 0; t < 9; ++t) {
-                    p32[(((size_t)(ci / 16) * 9 + t) * cout + R) * 16 + (ci % 16)] =
+                    // OIHW tap t = ky*3 + kx goes to packed slot kx*3 + ky: a kernel step is one
+                    // (plane, kx) with its three ky taps contiguous (conv3x3_mfma.hip.h)
+                    const int slot = (t % 3) * 3 + t / 3;
+                    p32[(((size_t)(ci / 16) * 9 + slot) * cout + R) * 16 + (ci % 16)] =
                         w[((size_t)R * cin + ci) * 9 + t];
-                    p16[(((size_t)(ci / 32) * 9 + t) * cout + R) * 32 + (ci % 32)] =
+                    p16[(((size_t)(ci / 32) * 9 + slot) * cout + R) * 32 + (ci % 32)] =
                         f32_to_bf16_rne(w[((size_t)co16 * cin + ci) * 9 + t]);
                 }
         }
