@@ -410,10 +410,43 @@ template <int BN, int TH, int TW, int MODE> struct ConvTile {
 constexpr int conv_wave_frags(int BN, int TH, int TW) { return TH * TW / 16 / (4 / (BN / 64)); }
 constexpr int conv_occupancy(int BN, int TH, int TW) { return conv_wave_frags(BN, TH, TW) == 4 ? 3 : 2; }
 
-// ---- epilogue shared by the conv kernels: y = relu(acc * scale + shift) -> blocked activation
-//      records (+ fused pool / head / split-K slab).  acc[m][n]: accumulator tile m (16 couts) x
-//      pixel fragment n of the wave (wc = cout half, wp = pixel group) of workgroup tile (b, y0, x0),
-//      cout tile ct, K slice `split`.
+// ---- accumulator set-up and epilogue shared by the conv kernels ---------------------------------
+// Eval-mode BatchNorm is folded on both sides of the K loop: its scale into the packed weights
+// (fiunet_load_weights) and its shift into the INITIAL value of the accumulators, so the epilogue is
+// just y = relu(acc).  Which couts a lane holds: accumulator tile m, register j of lane group lc is
+// MFMA row lc*4+j of that tile.  fp32: row r of tile m <-> cout m*16+r, so a lane's 4 registers are
+// one 16-B quarter of the tile's 64-B plane record.  bf16: the packed weight rows are permuted on the
+// host (fiunet.hip, `bf16_row_to_cout`) so that tiles 2g and 2g+1 together give the lane the 8
+// consecutive couts g*32+lc*8 .. +7: ONE 16-B store per lane and tile pair, and the 4 lane groups of
+// a pixel write its whole 64-B record (1 KiB contiguous per store instruction).
+template <typename T> __device__ __forceinline__ int conv_cout_ofs(int m, int lc)
+{
+    return sizeof(T) == 2 ? (m >> 1) * 32 + lc * 8 + (m & 1) * 4 : m * 16 + lc * 4;  // cout (within the wave) of register j = 0
+}
+
+template <typename T, int BN, int TH, int TW, int EPI>
+__device__ __forceinline__ void conv_acc_init(const ConvArgs& a, f32x4 (&acc)[4][conv_wave_frags(BN, TH, TW)],
+                                              int ct, int wc, int lc)
+{
+    constexpr int NF = conv_wave_frags(BN, TH, TW);
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+        f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
+        if constexpr (EPI != EPI_SPLITK) {  // K slices start from zero; splitk_finalize_kernel adds the shift
+            const float4 sh = *reinterpret_cast<const float4*>(a.shift + ct * BN + wc * 64 + conv_cout_ofs<T>(m, lc));
+            v = f32x4{sh.x, sh.y, sh.z, sh.w};
+        }
+#pragma unroll
+        for (int n = 0; n < NF; ++n) acc[m][n] = v;
+    }
+}
+
+// bf16 pair -> relu on the packed pair: for x < 0 (sign bit set, incl. -0.0) the int16 pattern is negative
+__device__ __forceinline__ unsigned relu_pk_bf16(unsigned p) { return pk_max_i16(p, 0u); }
+
+//      y = relu(acc) -> blocked activation records (+ fused pool / head / split-K slab).  acc[m][n]:
+//      accumulator tile m (16 couts) x pixel fragment n of the wave (wc = cout half, wp = pixel
+//      group) of workgroup tile (b, y0, x0), cout tile ct, K slice `split`.
 template <typename T, int BN, int TH, int TW, int EPI>
 __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x4 (&acc)[4][conv_wave_frags(BN, TH, TW)],
                                               int b, int y0, int x0, int ct, int split, int wc, int wp,
@@ -425,18 +458,8 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x4 (&acc)[4]
     constexpr int ROWS_W = NF / FR;
     constexpr int HNC = EPI == EPI_HEAD ? 1 : (EPI == EPI_HEAD3 ? 3 : 0);
     const int aH = a.H, aW = a.W;
-    // ---- epilogue: y = relu(acc * scale + shift) -> blocked activation records -------------------
-    // Which couts a lane holds: accumulator tile m, register j of lane group lc is MFMA row
-    // lc*4+j of that tile.  fp32: row r of tile m <-> cout m*16+r, so a lane's 4 registers are one
-    // 16-B quarter of the tile's 64-B plane record.  bf16: the packed weight rows are permuted on
-    // the host (fiunet.hip, `bf16_row_to_cout`) so that tiles 2g and 2g+1 together give the lane
-    // the 8 consecutive couts g*32+lc*8 .. +7: ONE 16-B store per lane and tile pair, and the 4
-    // lane groups of a pixel write its whole 64-B record (1 KiB contiguous per store instruction).
     constexpr bool PERM = sizeof(T) == 2;
     const int wbase_c = ct * BN + wc * 64;  // first cout of this wave
-    auto cofs = [&](int m) __attribute__((always_inline)) {  // cout (within the wave) of register j=0
-        return PERM ? (m >> 1) * 32 + lc * 8 + (m & 1) * 4 : m * 16 + lc * 4;
-    };
     if constexpr (EPI == EPI_SPLITK) {
         float* const slab = a.kslab + (size_t)split * a.B * aH * aW * a.Cout;
 #pragma unroll
@@ -447,30 +470,24 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x4 (&acc)[4]
                 float* o = slab + (((size_t)b * aH + y) * aW + x) * a.Cout + wbase_c;
 #pragma unroll
                 for (int m = 0; m < 4; ++m)
-                    *reinterpret_cast<float4*>(o + cofs(m)) =
+                    *reinterpret_cast<float4*>(o + conv_cout_ofs<T>(m, lc)) =
                         make_float4(acc[m][n][0], acc[m][n][1], acc[m][n][2], acc[m][n][3]);
             }
         }
         return;
-    }
-    float4 sc[4], sh[4];
-#pragma unroll
-    for (int m = 0; m < 4; ++m) {
-        sc[m] = *reinterpret_cast<const float4*>(a.scale + wbase_c + cofs(m));
-        sh[m] = *reinterpret_cast<const float4*>(a.shift + wbase_c + cofs(m));
     }
     float hw[HNC > 0 ? HNC : 1][4][4];
 #pragma unroll
     for (int c = 0; c < HNC; ++c)
 #pragma unroll
         for (int m = 0; m < 4; ++m) {
-            const float4 v = *reinterpret_cast<const float4*>(a.head_w + c * 64 + cofs(m));
+            const float4 v = *reinterpret_cast<const float4*>(a.head_w + c * 64 + conv_cout_ofs<T>(m, lc));
             hw[c][m][0] = v.x; hw[c][m][1] = v.y; hw[c][m][2] = v.z; hw[c][m][3] = v.w;
         }
     // record address = image base + plane * plane_stride + pixel * 64 + byte within the record
     const size_t plane_stride = (size_t)aH * aW * 64;
     const int plane0 = wbase_c / PL;                       // first output plane of this wave
-    const int rec_byte = PERM ? lc * 16 : lc * 16;         // this lane's 16 B of a 64-B record
+    const int rec_byte = lc * 16;                          // this lane's 16 B of a 64-B record
     char* const out_img = a.dst ? (char*)a.dst + (size_t)b * plane_stride * (a.Cout / PL) +
                                   (size_t)plane0 * plane_stride + rec_byte : nullptr;
     const int pH = aH >> 1, pW = aW >> 1;  // EPI_POOL: MaxPool2d(2) output size (floor)
@@ -482,58 +499,54 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x4 (&acc)[4]
         const int y = y0 + wp * ROWS_W + n / FR;
         const int x = x0 + (n % FR) * 16 + l15;
         const bool ok = (y < aH) && (x < aW);
-        float hsum[HNC > 0 ? HNC : 1] = {};
-        float v[4][4];
+        if constexpr (HNC > 0) {
+            // fused 1x1 head on the fp32 post-activation values (never rounded to bf16)
+            float hsum[HNC] = {};
 #pragma unroll
-        for (int m = 0; m < 4; ++m) {
-            v[m][0] = fmaf(acc[m][n][0], sc[m].x, sh[m].x);
-            v[m][1] = fmaf(acc[m][n][1], sc[m].y, sh[m].y);
-            v[m][2] = fmaf(acc[m][n][2], sc[m].z, sh[m].z);
-            v[m][3] = fmaf(acc[m][n][3], sc[m].w, sh[m].w);
-            if (a.relu) {
+            for (int m = 0; m < 4; ++m)
 #pragma unroll
-                for (int j = 0; j < 4; ++j) v[m][j] = fmaxf(v[m][j], 0.f);
-            }
+                for (int j = 0; j < 4; ++j) {
+                    const float v = a.relu ? fmaxf(acc[m][n][j], 0.f) : acc[m][n][j];
 #pragma unroll
-            for (int c = 0; c < HNC; ++c)
+                    for (int c = 0; c < HNC; ++c) hsum[c] = fmaf(v, hw[c][m][j], hsum[c]);
+                }
 #pragma unroll
-                for (int j = 0; j < 4; ++j) hsum[c] = fmaf(v[m][j], hw[c][m][j], hsum[c]);
-            if (EPI == EPI_POOL) {
-                // keep the post-activation values in acc: the 2x2 max below needs the row pair
-#pragma unroll
-                for (int j = 0; j < 4; ++j) acc[m][n][j] = v[m][j];
+            for (int c = 0; c < HNC; ++c) {
+                float s = hsum[c];
+                s += __shfl_xor(s, 16);
+                s += __shfl_xor(s, 32);
+                if (ok && lc == 0)
+                    a.head_out[(((size_t)b * HNC + c) * aH + y) * aW + x] = s + a.head_b[c];
             }
         }
         if (ok && out_img) {
             char* o = out_img + (size_t)(y * aW + x) * 64;
             if constexpr (PERM) {
 #pragma unroll
-                for (int g = 0; g < 2; ++g)
-                    *reinterpret_cast<uint4*>(o + g * plane_stride) = make_uint4(
-                        pack_bf16x2(v[2 * g][0], v[2 * g][1]), pack_bf16x2(v[2 * g][2], v[2 * g][3]),
-                        pack_bf16x2(v[2 * g + 1][0], v[2 * g + 1][1]),
-                        pack_bf16x2(v[2 * g + 1][2], v[2 * g + 1][3]));
+                for (int g = 0; g < 2; ++g) {
+                    uint4 pk = make_uint4(pack_bf16x2(acc[2 * g][n][0], acc[2 * g][n][1]),
+                                          pack_bf16x2(acc[2 * g][n][2], acc[2 * g][n][3]),
+                                          pack_bf16x2(acc[2 * g + 1][n][0], acc[2 * g + 1][n][1]),
+                                          pack_bf16x2(acc[2 * g + 1][n][2], acc[2 * g + 1][n][3]));
+                    if (a.relu) pk = make_uint4(relu_pk_bf16(pk.x), relu_pk_bf16(pk.y), relu_pk_bf16(pk.z), relu_pk_bf16(pk.w));
+                    *reinterpret_cast<uint4*>(o + g * plane_stride) = pk;
+                }
             } else {
 #pragma unroll
-                for (int m = 0; m < 4; ++m)
-                    *reinterpret_cast<float4*>(o + m * plane_stride) =
-                        make_float4(v[m][0], v[m][1], v[m][2], v[m][3]);
+                for (int m = 0; m < 4; ++m) {
+                    float4 v = make_float4(acc[m][n][0], acc[m][n][1], acc[m][n][2], acc[m][n][3]);
+                    if (a.relu) v = make_float4(fmaxf(v.x, 0.f), fmaxf(v.y, 0.f), fmaxf(v.z, 0.f), fmaxf(v.w, 0.f));
+                    *reinterpret_cast<float4*>(o + m * plane_stride) = v;
+                }
             }
-        }
-#pragma unroll
-        for (int c = 0; c < HNC; ++c) {
-            float s = hsum[c];
-            s += __shfl_xor(s, 16);
-            s += __shfl_xor(s, 32);
-            if (ok && lc == 0)
-                a.head_out[(((size_t)b * HNC + c) * aH + y) * aW + x] = s + a.head_b[c];
         }
     }
     if (EPI == EPI_POOL) {
         // MaxPool2d(2) of this conv's output (unet.py:28), fused here so the consumer conv reads a
         // ready tensor by LDS-DMA: tile origins are even, a wave owns whole row pairs (fragments n
         // and n+FR) and the column partner is the neighbouring lane (l15 ^ 1).
-        // max(round(a), round(b)) == round(max(a, b)), so this equals pooling the stored tensor.
+        // relu and the bf16 rounding are monotonic, so max-then-relu-then-round of the raw sums
+        // equals pooling the stored tensor.
 #pragma unroll
         for (int n = 0; n < NF; ++n) {
             if (((n / FR) & 1) != 0) continue;  // upper row of each pair only
@@ -550,11 +563,15 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x4 (&acc)[4]
                     for (int j = 0; j < 4; ++j) {
                         const float cm = fmaxf(acc[m][n][j], acc[m][n + FR][j]);
                         r[j] = fmaxf(cm, __uint_as_float(dpp_swap_pairs(__float_as_uint(cm))));
+                        if (a.relu) r[j] = fmaxf(r[j], 0.f);
                     }
                     if (okp) *reinterpret_cast<float4*>(o + m * pplane_stride) = make_float4(r[0], r[1], r[2], r[3]);
                 }
             } else {
-                // values are >= 0 (post-ReLU): packed int16 max on the rounded bf16 pairs
+                // Packed int16 max on the rounded bf16 pairs.  Among non-negative patterns it is the
+                // float max; a negative pattern (sign bit) loses against every non-negative one, so
+                // the result is the true maximum whenever that is >= 0 and SOME negative value
+                // otherwise -- which the final relu turns into 0 either way: relu(max) exactly.
 #pragma unroll
                 for (int g = 0; g < 2; ++g) {
                     unsigned r[4];
@@ -567,6 +584,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x4 (&acc)[4]
                                                        pack_bf16x2(acc[m][n + FR][2], acc[m][n + FR][3]));
                         r[2 * h] = pk_max_i16(a0, dpp_swap_pairs(a0));
                         r[2 * h + 1] = pk_max_i16(a1, dpp_swap_pairs(a1));
+                        if (a.relu) { r[2 * h] = relu_pk_bf16(r[2 * h]); r[2 * h + 1] = relu_pk_bf16(r[2 * h + 1]); }
                     }
                     if (okp) *reinterpret_cast<uint4*>(o + g * pplane_stride) = make_uint4(r[0], r[1], r[2], r[3]);
                 }
@@ -625,10 +643,7 @@ __global__ __launch_bounds__(256, conv_occupancy(BN, TH, TW)) void conv3x3_mfma_
     const int wc = wave % WAVES_C, wp = wave / WAVES_C;
 
     f32x4 acc[4][NF];
-#pragma unroll
-    for (int m = 0; m < 4; ++m)
-#pragma unroll
-        for (int n = 0; n < NF; ++n) acc[m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+    conv_acc_init<T, BN, TH, TW, EPI>(a, acc, ct, wc, lc);  // BatchNorm shift (scale is in the weights)
 
     // per-lane LDS read offsets (everything else is an immediate)
     const int a_off = (wc * 64 + l15) * 64 + ((lc ^ swz(l15)) << 4);  // within a weight ring slot
@@ -784,12 +799,14 @@ __global__ __launch_bounds__(256, conv_occupancy(BN, TH, TW)) void conv3x3_mfma_
                                  (size_t)(plane - p0) * a.lowH * a.lowW * 64;
         int opq = 0;
         asm volatile("" : "+s"(opq));
+        int l4 = (lane & 3) << 4;          // opaque: hipcc would otherwise form lsrc + l4 as a 64-bit
+        asm volatile("" : "+v"(l4));       // per-lane pointer ahead of the K loop (and spill it)
 #pragma unroll 1
         for (int j = wave; j < Tile::LR_PIECES; j += 4) {
             const int row = j * 16 + (lane >> 2) + opq;
             const int r = row / LRP, c = row - r * LRP;
             const int gy = min(lr_y + min(r, LRH - 1), a.lowH - 1), gx = min(lr_x + c, a.lowW - 1);
-            const char* src = lsrc + (unsigned)(gy * a.lowW + gx) * 64u + ((lane & 3) << 4);
+            const char* src = lsrc + ((unsigned)(gy * a.lowW + gx) * 64u + (unsigned)l4);
             glds16(src, __builtin_amdgcn_readfirstlane(lds_w_addr + (unsigned)(stg_off + j * 1024)));
         }
         lds_dma_wait_all();
@@ -911,11 +928,13 @@ __global__ __launch_bounds__(256, conv_occupancy(BN, TH, TW)) void conv3x3_mfma_
         if constexpr (MODE == SRC_STEM) {
             // A operands (weights) of the plane's two 16-cout tiles, hi and lo parts
             uint4 wh[2], wl[2];
+            int lane_ofs = l15 * 64 + lc * 16;     // opaque: keeps hipcc from forming the 64-bit
+            asm volatile("" : "+v"(lane_ofs));     // per-lane pointer before the K loop and spilling it
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
-                const int row = (plane * 2 + h) * 16 + l15;
-                wh[h] = ldg16((const char*)a.stem_w + row * 64 + lc * 16);
-                wl[h] = ldg16((const char*)a.stem_w + 64 * 64 + row * 64 + lc * 16);
+                const int ofs = (plane * 2 + h) * 16 * 64 + lane_ofs;
+                wh[h] = ldg16((const char*)a.stem_w + ofs);
+                wl[h] = ldg16((const char*)a.stem_w + 64 * 64 + ofs);
             }
             float4 ssc[2], ssh[2];
 #pragma unroll

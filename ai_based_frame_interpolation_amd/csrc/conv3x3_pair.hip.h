@@ -89,10 +89,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_pair_kernel(const ConvArgs a)
     const int wc = wave % WAVES_C, wp = wave / WAVES_C;
 
     f32x4 acc[4][NF];
-#pragma unroll
-    for (int m = 0; m < 4; ++m)
-#pragma unroll
-        for (int n = 0; n < NF; ++n) acc[m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+    conv_acc_init<T, BN, TH, TW, EPI>(a, acc, ct, wc, lc);
 
     const int a_off = (wc * 64 + l15) * 64 + ((lc ^ swz(l15)) << 4);
     int b_off[3];
@@ -171,7 +168,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_pair_kernel(const ConvArgs a)
             if (step + 1 < nsteps) issue_w(step + 1);
             if (kx == 0 && more) gather_plane(plane + 1, par ^ 1);
             const char* wcur = lds_w + (step & 1) * Tile::W_BYTES + a_off;
-            constexpr bool ROLL = sizeof(T) == 2 && FR == 2;  // rolling row window: see conv3x3_mfma_kernel
+            constexpr bool ROLL = sizeof(T) == 2 && FR == 2 && EPI != EPI_POOL;  // rolling row window: see conv3x3_mfma_kernel (the pooled variant has no registers for it here)
             if constexpr (ROLL) {
                 uint4 xb[ROWS_W + 2][FR];
                 auto load_row = [&](int i) __attribute__((always_inline)) {

@@ -302,7 +302,7 @@ int launch_conv_maybe_split(ConvArgs a, hipStream_t s)
             if (rc) return rc;
             const size_t n = (size_t)a.B * a.H * a.W * (a.Cout / Elem<T>::NE);
             hipLaunchKernelGGL((splitk_finalize_kernel<T>), dim3(grid_for(n)), dim3(256), 0, s, a.kslab,
-                               ksplit, a.scale, a.shift, (T*)a.dst, a.B, a.H, a.W, a.Cout, a.relu);
+                               ksplit, (const float*)nullptr, a.shift, (T*)a.dst, a.B, a.H, a.W, a.Cout, a.relu);
             HIP_TRY(hipGetLastError());
             if constexpr (EPI == EPI_POOL) {
                 const size_t np = (size_t)a.B * (a.H / 2) * (a.W / 2) * (a.Cout * sizeof(T) / 16);
@@ -659,10 +659,12 @@ int fiunet_load_weights(fiunet_ctx* ctx, int n, const char* const* names,
                     // OIHW tap t = ky*3 + kx goes to packed slot kx*3 + ky: a kernel step is one
                     // (plane, kx) with its three ky taps contiguous (conv3x3_mfma.hip.h)
                     const int slot = (t % 3) * 3 + t / 3;
+                    // BatchNorm's scale goes into the weights (one fp32 product, then the bf16
+                    // rounding for the bf16 copy), its shift into the accumulators' initial value
                     p32[(((size_t)(ci / 16) * 9 + slot) * cout + R) * 16 + (ci % 16)] =
-                        w[((size_t)R * cin + ci) * 9 + t];
+                        w[((size_t)R * cin + ci) * 9 + t] * sc[R];
                     p16[(((size_t)(ci / 32) * 9 + slot) * cout + R) * 32 + (ci % 32)] =
-                        f32_to_bf16_rne(w[((size_t)co16 * cin + ci) * 9 + t]);
+                        f32_to_bf16_rne(w[((size_t)co16 * cin + ci) * 9 + t] * sc[co16]);
                 }
         }
         if ((rc = dev_upload(ctx, p32.data(), nel * 4, &cw.w_f32))) return rc;

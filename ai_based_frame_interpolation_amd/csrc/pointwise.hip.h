@@ -216,7 +216,7 @@ __global__ __launch_bounds__(256) void splitk_finalize_kernel(const float* __res
         }
 #pragma unroll
         for (int e = 0; e < NE; ++e) {
-            v[e] = fmaf(v[e], scale[c0 + e], shift[c0 + e]);
+            v[e] = scale ? fmaf(v[e], scale[c0 + e], shift[c0 + e]) : v[e] + shift[c0 + e];  // scale == nullptr: folded into the weights
             if (relu) v[e] = fmaxf(v[e], 0.f);
         }
         const size_t b = pix / ((size_t)H * W), r = pix - b * (size_t)H * W;
