@@ -11,9 +11,9 @@ never defines: `.interpolate_frames(img1, img2)` and
 `.interpolate_video(input, output, factor)`.
 
 The arithmetic of pre/post-processing and the network runs in HIP kernels; this file is
-plumbing (file I/O, shapes, batching).  No cv2/imageio in this image, so image files are read
-through cv2 only if it happens to be importable; `.npy` arrays and binary PGM/PPM are always
-supported, and videos are raw `.npy` frame stacks [N,H,W] / [N,H,W,3] uint8.
+plumbing (file I/O, shapes, batching).  No cv2/imageio in this image: image files go through cv2 if
+it happens to be importable, else through imageio_lite (PNG, BMP, PGM/PPM, `.npy`; cv2.resize's
+fixed-point INTER_LINEAR restated); videos are raw `.npy` frame stacks [N,H,W] / [N,H,W,3] uint8.
 """
 from __future__ import annotations
 
@@ -21,55 +21,36 @@ import os
 
 import numpy as np
 import torch
-import torch.nn.functional as F
 
-from . import _native
+from struct import error as struct_error
+from zlib import error as zlib_error
+
+from . import _native, imageio_lite
 from .unet import FrameInterpolationUNet
 
 
 def _read_gray(path: str) -> np.ndarray:
-    ext = os.path.splitext(path)[1].lower()
-    if ext == ".npy":
-        img = np.load(path)
-    elif ext in (".pgm", ".ppm"):
-        with open(path, "rb") as f:
-            data = f.read()
-        tok, pos = [], 0
-        while len(tok) < 4:  # magic, width, height, maxval
-            while data[pos:pos + 1].isspace():
-                pos += 1
-            if data[pos:pos + 1] == b"#":
-                pos = data.index(b"\n", pos) + 1
-                continue
-            end = pos
-            while not data[end:end + 1].isspace():
-                end += 1
-            tok.append(data[pos:end]); pos = end
-        pos += 1
-        w, h = int(tok[1]), int(tok[2])
-        ch = 3 if tok[0] == b"P6" else 1
-        img = np.frombuffer(data, dtype=np.uint8, count=w * h * ch, offset=pos).reshape(h, w, ch)
-        img = img[..., 0] if ch == 1 else img
-    else:
-        try:
-            import cv2  # type: ignore
-        except ImportError:
-            return None
+    """cv2.imread(path, cv2.IMREAD_GRAYSCALE) (inference.py:23): OpenCV when it is installed, else the
+    readers of imageio_lite (PNG, BMP, PGM/PPM, .npy).  None when the file cannot be decoded."""
+    try:
+        import cv2  # type: ignore
         return cv2.imread(path, cv2.IMREAD_GRAYSCALE)
-    if img.ndim == 3:  # cv2's BGR->GRAY weights are for decoded colour files; here: RGB mean
-        img = np.round(img[..., :3].astype(np.float32) @ np.array([0.299, 0.587, 0.114], np.float32))
-    return np.clip(img, 0, 255).astype(np.uint8)
+    except ImportError:
+        pass
+    try:
+        return imageio_lite.read_gray(path)
+    except (ValueError, KeyError, struct_error, zlib_error, OSError):
+        return None
 
 
 def _resize_linear_u8(img: np.ndarray, target_size) -> np.ndarray:
-    """cv2.resize(img, (W, H)) default INTER_LINEAR: half-pixel centres, edge clamp, result
-    rounded to uint8.  Host glue, not part of the device hot path."""
-    tw, th = int(target_size[0]), int(target_size[1])
-    if img.shape[0] == th and img.shape[1] == tw:
-        return img
-    t = torch.from_numpy(img.astype(np.float32))[None, None]
-    r = F.interpolate(t, size=(th, tw), mode="bilinear", align_corners=False)
-    return r[0, 0].round().clamp(0, 255).to(torch.uint8).numpy()
+    """cv2.resize(img, (W, H)) (inference.py:29, default INTER_LINEAR): OpenCV when installed, else its
+    fixed-point algorithm restated in imageio_lite.  Host glue, not part of the device hot path."""
+    try:
+        import cv2  # type: ignore
+        return cv2.resize(img, (int(target_size[0]), int(target_size[1])))
+    except ImportError:
+        return imageio_lite.resize_linear_u8(img, target_size)
 
 
 def preprocess_image(image_path, target_size=(256, 256)):
