@@ -314,3 +314,24 @@ def test_host_resident_video_loop_matches_device_loop(model, dev):
     a = P.interpolate_sequence_host(model, fr, batch=4)
     b = P.interpolate_sequence(model, fr.to(dev), batch=4).cpu()
     assert a.shape == (21, 40, 64) and torch.equal(a, b)
+
+
+def test_random_shapes_fp32_and_bf16_vs_oracle(model, dev, seeded_sd):
+    """Seeded sweep over frame shapes that are not multiples of the tile sizes (partial tiles in both
+    directions, odd pyramid levels with the asymmetric F.pad, one and several tiles per level) and
+    batch sizes, both precisions, against the oracle."""
+    rng = np.random.default_rng(2024)
+    shapes = [(int(rng.integers(1, 4)), int(rng.integers(16, 150)), int(rng.integers(16, 200))) for _ in range(14)]
+    shapes += [(1, 16, 199), (2, 149, 16), (1, 97, 131), (1, 64, 33)]
+    for b, h, w in shapes:
+        f1, f2 = O.make_frames(7000 + 13 * h + w, b, h, w)
+        ref = O.unet_forward(seeded_sd, f1, f2)
+        model.precision = "fp32"
+        out = model(f1.to(dev), f2.to(dev)).cpu()
+        d = (out - ref).abs().max().item()
+        assert d <= FP32_TOL and d <= 1e-4 * max(1.0, ref.abs().max().item()), (b, h, w, d)
+        model.precision = "bf16"
+        out = model(f1.to(dev), f2.to(dev)).cpu()
+        rel = ((out - ref).norm() / ref.norm()).item()
+        assert rel <= 2.5e-2 and torch.isfinite(out).all(), (b, h, w, rel)
+    model.precision = "fp32"
