@@ -728,11 +728,23 @@ __global__ __launch_bounds__(256, conv_occupancy(BN, TH, TW)) void conv3x3_mfma_
         } else {
             int opq = 0;  // opaque zero: keeps the per-piece address math out of the K loop's
             asm volatile("" : "+s"(opq));  // invariant-hoisting (it would pin a VGPR per piece)
+            // A wave's pieces are 64 in-tile pixels apart: (py, px) and the linear pixel index
+            // advance by constants with one conditional row wrap, so a piece costs adds and
+            // compares only (no division, no multiply); 64 rows keep the swizzle phase, and
+            // NPIECE * 16 == THP * TWP exactly, so py stays inside the in-tile.
+            constexpr int DY = 64 / TWP, DX = 64 % TWP;
+            const int row0 = wave * 16 + (lane >> 2) + opq;
+            int py = row0 / TWP, px = row0 - py * TWP;
+            int y = y0 - 1 + py, x = x0 - 1 + px;
+            unsigned lin = (unsigned)(y * aW + x) * 64u + (((lane & 3) ^ swz(row0)) << 4);
+            const unsigned dlin = (unsigned)(DY * aW + DX) * 64u, dwrap = (unsigned)(aW - TWP) * 64u;
 #pragma unroll 1
             for (int j = wave; j < NPIECE; j += 4) {
-                const unsigned off = piece_off(j, opq);
-                const char* src = off != ~0u ? base + off : zero_src;
+                const bool ok = (px < TW + 2) & ((unsigned)y < (unsigned)aH) & ((unsigned)x < (unsigned)aW);
+                const char* src = ok ? base + lin : zero_src;
                 glds16(src, __builtin_amdgcn_readfirstlane(lds_in_addr + (unsigned)j * 1024u));
+                px += DX; x += DX; y += DY; lin += dlin;
+                if (px >= TWP) { px -= TWP; x -= TWP; y += 1; lin += dwrap; }
             }
         }
     };
