@@ -84,9 +84,8 @@ struct ConvArgs {
     // in-tile gather of the NEXT conv, so its 64-channel output never goes to HBM.
     const float* f1;          // frame1 [B][1][H][W] fp32
     const float* f2;          // frame2
-    const void* stem_w;       // [2 (hi, lo)][64 couts][32 k] bf16; k = dy*8 + dx*2 + frame, zero for dx = 3 or dy = 3
-    const float* stem_scale;  // [64]
-    const float* stem_shift;  // [64]
+    const void* stem_w;       // [2 (hi, lo)][64 couts][32 k] bf16 of w * bn_scale; k = dy*8 + dx*2 + frame, zero for
+                              // dx = 3 or dy = 3 except k = 24, which holds the BatchNorm shift (its operand is 1.0)
     // EPI_SPLITK: the K loop (planes) is cut into `ksplit` slices handled by different workgroups;
     // slice s stores its raw fp32 partial sums to kslab[s][B*H*W][Cout]; splitk_finalize_kernel adds
     // the slices in order (deterministic) and applies scale/shift/ReLU.
@@ -399,7 +398,11 @@ template <int BN, int TH, int TW, int MODE> struct ConvTile {
     // pixel column (same for every plane, so it is evaluated once per tile, not per plane)
     static constexpr int TAB_OFF = PATCH_OFF + ((PATCH_BYTES + 255) / 256) * 256;
     static constexpr int TAB_BYTES = MODE == SRC_CONCAT_UP ? ((THP + TW + 2) * 16 + 255) / 256 * 256 : 0;
-    static constexpr int LDS_BYTES = TAB_OFF + TAB_BYTES;
+    // SRC_STEM: plane 1's stem weights (hi and lo halves of two 16-cout tiles), parked here by
+    // LDS-DMA at kernel start so the plane boundary does not wait on a global load
+    static constexpr int STEMW_OFF = TAB_OFF + TAB_BYTES;
+    static constexpr int STEMW_BYTES = MODE == SRC_STEM ? 4096 : 0;
+    static constexpr int LDS_BYTES = STEMW_OFF + STEMW_BYTES;
     static_assert(LDS_BYTES <= 80 * 1024, "two workgroups must fit in the CU's 160 KiB of LDS");
 };
 
@@ -930,69 +933,108 @@ __global__ __launch_bounds__(256, conv_occupancy(BN, TH, TW)) void conv3x3_mfma_
 #pragma unroll
             for (int k = 0; k < NB; ++k) {
                 const int i = tid + k * 256;
-                const unsigned hi = pack_bf16x2(v[k], 0.f) & 0xffffu;
+                // the 64-B pad behind the hi image holds 1.0s (lo: zeros): the operand of the bias slot
+                const unsigned hi = i < PH * PW * 2 ? pack_bf16x2(v[k], 0.f) & 0xffffu : 0x3f80u;
                 const unsigned lo = pack_bf16x2(v[k] - __uint_as_float(hi << 16), 0.f) & 0xffffu;
-                if (i < NE) { ph[i] = (unsigned short)hi; pl[i] = (unsigned short)lo; }
+                if (i < NE) { ph[i] = (unsigned short)hi; pl[i] = (unsigned short)(i < PH * PW * 2 ? lo : 0u); }
             }
         }
     };
-    auto gather_plane_stem = [&](int plane) __attribute__((always_inline)) {
+    // The plane's A operands: two 16-cout tiles, hi and lo parts, BatchNorm scale folded in on the
+    // host and the BatchNorm shift riding in k-slot 24 (lane group 3, whose data operand is 1.0).
+    // Plane 0's come straight from global memory, requested before the patch is staged; plane 1's
+    // are parked in LDS by DMA at kernel start and picked up at the plane boundary.
+    struct StemW { uint4 wh[2], wl[2]; };
+    StemW stem_w0;
+    auto stem_load = [&](StemW& w) __attribute__((always_inline)) {
         if constexpr (MODE == SRC_STEM) {
-            // A operands (weights) of the plane's two 16-cout tiles, hi and lo parts
-            uint4 wh[2], wl[2];
             int lane_ofs = l15 * 64 + lc * 16;     // opaque: keeps hipcc from forming the 64-bit
             asm volatile("" : "+v"(lane_ofs));     // per-lane pointer before the K loop and spilling it
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
-                const int ofs = (plane * 2 + h) * 16 * 64 + lane_ofs;
-                wh[h] = ldg16((const char*)a.stem_w + ofs);
-                wl[h] = ldg16((const char*)a.stem_w + 64 * 64 + ofs);
+                w.wh[h] = ldg16((const char*)a.stem_w + h * 1024 + lane_ofs);
+                w.wl[h] = ldg16((const char*)a.stem_w + 4096 + h * 1024 + lane_ofs);
             }
-            float4 ssc[2], ssh[2];
+            // plane 1: wave w moves [hi h0 | hi h1 | lo h0 | lo h1][w], lane-linear
+            glds16((const char*)a.stem_w + (wave >> 1) * 4096 + (2 + (wave & 1)) * 1024 + lane * 16,
+                   __builtin_amdgcn_readfirstlane(lds_in_addr + (unsigned)(Tile::STEMW_OFF + wave * 1024)));
+        }
+    };
+    auto stem_parked = [&](StemW& w) __attribute__((always_inline)) {
+        if constexpr (MODE == SRC_STEM) {
+            const char* const base = smem + Tile::STEMW_OFF + l15 * 64 + lc * 16;
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
-                ssc[h] = *reinterpret_cast<const float4*>(a.stem_scale + (plane * 2 + h) * 16 + lc * 4);
-                ssh[h] = *reinterpret_cast<const float4*>(a.stem_shift + (plane * 2 + h) * 16 + lc * 4);
-            }
-            const int dy = min(lc, 2);  // lane group 3 multiplies zero weights: any finite data
-#pragma unroll 1
-            for (int q = wave; q * 16 < NIN; q += 4) {
-                const int i = min(q * 16 + l15, NIN - 1);
-                const int py = i / (TW + 2), px = i - py * (TW + 2);
-                const unsigned* const sh32 = reinterpret_cast<const unsigned*>(patch) + (py + dy) * PW + px;
-                const unsigned* const sl32 = reinterpret_cast<const unsigned*>(patch + PATCH_HALF) + (py + dy) * PW + px;
-                const uint4 bh = make_uint4(sh32[0], sh32[1], sh32[2], sh32[3]);
-                const uint4 bl = make_uint4(sl32[0], sl32[1], sl32[2], sl32[3]);
-                const int y = y0 - 1 + py, x = x0 - 1 + px;
-                const bool live = q * 16 + l15 < NIN;
-                const bool ok = live & (y >= 0) & (y < aH) & (x >= 0) & (x < aW);
-                const int row = py * TWP + px;
-#pragma unroll
-                for (int h = 0; h < 2; ++h) {
-                    f32x4 s4 = f32x4{0.f, 0.f, 0.f, 0.f};
-                    mma_chunk<T>(s4, wl[h], bh);
-                    mma_chunk<T>(s4, wh[h], bl);
-                    mma_chunk<T>(s4, wh[h], bh);
-                    float o[4];
-                    o[0] = fmaxf(fmaf(s4[0], ssc[h].x, ssh[h].x), 0.f);
-                    o[1] = fmaxf(fmaf(s4[1], ssc[h].y, ssh[h].y), 0.f);
-                    o[2] = fmaxf(fmaf(s4[2], ssc[h].z, ssh[h].z), 0.f);
-                    o[3] = fmaxf(fmaf(s4[3], ssc[h].w, ssh[h].w), 0.f);
-                    // channels (h*16 + lc*4 .. +3) of the plane: chunk 2h + (lc>>1), 8-B half lc&1
-                    const int ch = 2 * h + (lc >> 1);
-                    const uint2 pk = ok ? make_uint2(pack_bf16x2(o[0], o[1]), pack_bf16x2(o[2], o[3]))
-                                        : make_uint2(0u, 0u);
-                    if (live)
-                        *reinterpret_cast<uint2*>(lds_in + row * 64 + ((ch ^ swz(row)) << 4) + (lc & 1) * 8) = pk;
-                }
+                w.wh[h] = *reinterpret_cast<const uint4*>(base + h * 1024);
+                w.wl[h] = *reinterpret_cast<const uint4*>(base + 2048 + h * 1024);
             }
         }
     };
-    auto gather_plane = [&](int plane, int idle_slot) __attribute__((always_inline)) {
+    auto gather_plane_stem = [&](const StemW& w) __attribute__((always_inline)) {
+        if constexpr (MODE == SRC_STEM) {
+            // lane group 3 (k = 24..31) reads the row of 1.0s behind the hi image / zeros behind lo
+            const int drow = lc < 3 ? lc * PW : PH * PW;
+            // B operands of fragment q (16 in-tile pixels) + where its results go: dst < 0 = lane
+            // beyond the in-tile, bit 30 = pixel outside the image (stores zeros)
+            auto fetch = [&](int q, uint4& bh, uint4& bl, int& dst) __attribute__((always_inline)) {
+                const int i = min(q * 16 + l15, NIN - 1);
+                const int py = i / (TW + 2), px = i - py * (TW + 2);
+                const int e = lc < 3 ? py * PW + px + drow : drow;
+                const unsigned* const sh32 = reinterpret_cast<const unsigned*>(patch) + e;
+                const unsigned* const sl32 = reinterpret_cast<const unsigned*>(patch + PATCH_HALF) + e;
+                bh = make_uint4(sh32[0], sh32[1], sh32[2], sh32[3]);
+                bl = make_uint4(sl32[0], sl32[1], sl32[2], sl32[3]);
+                const int y = y0 - 1 + py, x = x0 - 1 + px;
+                const bool ok = ((unsigned)y < (unsigned)aH) & ((unsigned)x < (unsigned)aW);
+                const int row = py * TWP + px;
+                dst = q * 16 + l15 < NIN ? (row | (ok ? 0 : 1 << 30)) : -1;
+            };
+            uint4 bh, bl;
+            int dst;
+            fetch(wave, bh, bl, dst);
+#pragma unroll 1
+            for (int q = wave; q * 16 < NIN; q += 4) {
+                uint4 nbh, nbl;
+                int ndst;
+                fetch(q + 4, nbh, nbl, ndst);  // next fragment's operands fly during this one's MFMAs
+                f32x4 s4[2];
+#pragma unroll
+                for (int h = 0; h < 2; ++h) s4[h] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int h = 0; h < 2; ++h) mma_chunk<T>(s4[h], w.wl[h], bh);
+#pragma unroll
+                for (int h = 0; h < 2; ++h) mma_chunk<T>(s4[h], w.wh[h], bl);
+#pragma unroll
+                for (int h = 0; h < 2; ++h) mma_chunk<T>(s4[h], w.wh[h], bh);
+                const int row = dst & 0xffff;
+                const bool zero = (dst >> 30) & 1;
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    // channels (h*16 + lc*4 .. +3) of the plane: chunk 2h + (lc>>1), 8-B half lc&1
+                    const int ch = 2 * h + (lc >> 1);
+                    const unsigned p0 = relu_pk_bf16(pack_bf16x2(s4[h][0], s4[h][1]));
+                    const unsigned p1 = relu_pk_bf16(pack_bf16x2(s4[h][2], s4[h][3]));
+                    const uint2 pk = zero ? make_uint2(0u, 0u) : make_uint2(p0, p1);
+                    if (dst >= 0)
+                        *reinterpret_cast<uint2*>(lds_in + row * 64 + ((ch ^ swz(row)) << 4) + (lc & 1) * 8) = pk;
+                }
+                bh = nbh; bl = nbl; dst = ndst;
+            }
+        }
+    };
+    auto gather_plane = [&](int plane, int idle_slot, bool first) __attribute__((always_inline)) {
 #ifdef FIUNET_DIAG_NO_GATHER  // timing diagnostic: compute side alone (stale LDS, results are garbage)
         return;
 #endif
-        if constexpr (MODE == SRC_STEM) gather_plane_stem(plane);
+        if constexpr (MODE == SRC_STEM) {  // exactly two planes (64 stem channels)
+            if (first) {
+                gather_plane_stem(stem_w0);
+            } else {
+                StemW w1;
+                stem_parked(w1);
+                gather_plane_stem(w1);
+            }
+        }
         else if (MODE == SRC_DIRECT || plane < p0) gather_plane_dma(plane);
         else gather_plane_up(plane, idle_slot);
     };
@@ -1003,10 +1045,11 @@ __global__ __launch_bounds__(256, conv_occupancy(BN, TH, TW)) void conv3x3_mfma_
     // W(0) goes to slot 0, so slot 1 (+ spare) is the idle staging area for plane 0
     issue_w(0);
     if constexpr (MODE == SRC_STEM) {
+        stem_load(stem_w0);
         stage_patch();
         __syncthreads();
     }
-    gather_plane(pbeg, 1);
+    gather_plane(pbeg, 1, true);
     lds_dma_wait_all();
     __syncthreads();
     STAMP(1);
@@ -1078,7 +1121,7 @@ __global__ __launch_bounds__(256, conv_occupancy(BN, TH, TW)) void conv3x3_mfma_
             STAMP(2);
             if (kx == 2 && plane + 1 < pend) {
                 __syncthreads();  // every wave is done with this plane's in-tile and with W(step)
-                gather_plane(plane + 1, step & 1);
+                gather_plane(plane + 1, step & 1, false);
                 lds_dma_wait_all();
                 __syncthreads();
                 STAMP(4);

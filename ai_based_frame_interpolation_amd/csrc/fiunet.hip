@@ -175,7 +175,7 @@ struct fiunet_ctx {
     float* head_w = nullptr;  // [cf][64]
     float* head_b = nullptr;  // [cf]
     void* zero_page = nullptr;  // 256 zero bytes (LDS-DMA source for conv padding)
-    void* stem_w_split = nullptr;  // gray stem weights as bf16 hi/lo pairs [2][64][32] (fused stem)
+    void* stem_w_split = nullptr;  // gray stem weights x BatchNorm scale as bf16 hi/lo pairs [2][64][32] (fused stem)
     unsigned long long* stamps = nullptr;  // per-wave cycle records (diagnostic -DFIUNET_STAMP builds)
     int stamp_layer = -1;
     std::vector<void*> owned;
@@ -491,7 +491,6 @@ int forward_impl(fiunet_ctx* ctx, const float* f1, const float* f2, float* out, 
             mode = SRC_STEM;
             a.f1 = f1; a.f2 = f2;
             a.stem_w = ctx->stem_w_split;
-            a.stem_scale = ctx->conv[0].scale; a.stem_shift = ctx->conv[0].shift;
         }
         if (unfused && mode == SRC_CONCAT_UP) {
             const size_t n = (size_t)B * a.H * a.W * ((a.C0 + a.C1) * sizeof(T) / 16);
@@ -637,7 +636,7 @@ int fiunet_load_weights(fiunet_ctx* ctx, int n, const char* const* names,
                     for (int k = 0; k < 24; ++k) {
                         const int dy = k >> 3, dx = (k >> 1) & 3, f = k & 1;
                         if (dx == 3) continue;
-                        const float v = w[((size_t)co * 2 + f) * 9 + dy * 3 + dx];
+                        const float v = w[((size_t)co * 2 + f) * 9 + dy * 3 + dx] * sc[co];  // BatchNorm scale folded in
                         const uint16_t hi = f32_to_bf16_rne(v);
                         uint32_t hb = (uint32_t)hi << 16;
                         float hf;
@@ -645,6 +644,14 @@ int fiunet_load_weights(fiunet_ctx* ctx, int n, const char* const* names,
                         sp[(size_t)co * 32 + k] = hi;
                         sp[(size_t)64 * 32 + co * 32 + k] = f32_to_bf16_rne(v - hf);
                     }
+                for (int co = 0; co < 64; ++co) {  // k = 24: BatchNorm shift (the kernel feeds 1.0 there)
+                    const uint16_t hi = f32_to_bf16_rne(sh[co]);
+                    uint32_t hb = (uint32_t)hi << 16;
+                    float hf;
+                    std::memcpy(&hf, &hb, 4);
+                    sp[(size_t)co * 32 + 24] = hi;
+                    sp[(size_t)64 * 32 + co * 32 + 24] = f32_to_bf16_rne(sh[co] - hf);
+                }
                 if ((rc = dev_upload(ctx, sp.data(), sp.size() * 2, &ctx->stem_w_split))) return rc;
             }
             continue;
