@@ -446,6 +446,13 @@ __device__ __forceinline__ void conv_acc_init(const ConvArgs& a, f32x4 (&acc)[4]
 
 // bf16 pair -> relu on the packed pair: for x < 0 (sign bit set, incl. -0.0) the int16 pattern is negative
 __device__ __forceinline__ unsigned relu_pk_bf16(unsigned p) { return pk_max_i16(p, 0u); }
+// sum += max(x, lo) * w: v_max_f32 + v_fmac_f32 as one block (fmaxf() costs a canonicalising
+// v_max(x, x) in front, and a lone inline-asm v_max an s_nop behind)
+__device__ __forceinline__ void relu_fma(float& sum, float x, float lo, float w)
+{
+    float t;
+    asm("v_max_f32 %1, %3, %2\n\tv_fmac_f32 %0, %1, %4" : "+v"(sum), "=&v"(t) : "v"(x), "v"(lo), "v"(w));
+}
 
 //      y = relu(acc) -> blocked activation records (+ fused pool / head / split-K slab).  acc[m][n]:
 //      accumulator tile m (16 couts) x pixel fragment n of the wave (wc = cout half, wp = pixel
@@ -497,31 +504,55 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x4 (&acc)[4]
     const size_t pplane_stride = (size_t)pH * pW * 64;
     char* const pool_img = EPI == EPI_POOL ? (char*)a.pool_dst + (size_t)b * pplane_stride * (a.Cout / PL) +
                                              (size_t)plane0 * pplane_stride + rec_byte : nullptr;
+    if constexpr (HNC > 0) {
+        // Fused 1x1 head on the fp32 post-activation values (never rounded to bf16).  Every lane sums
+        // its 16 couts for each of the 8 fragments; the four lane groups of a pixel are then combined
+        // by a transposing reduction (v_permlane16_swap / v_permlane32_swap: 6 swaps instead of 16
+        // bpermutes, same (lc0 + lc1) + (lc2 + lc3) order), which leaves fragments nb, nb + 1 complete
+        // in lane group lc: all 64 lanes store, 2 dwords each.
+        static_assert(HNC == 0 || NF == 8, "head reduction is written for 8 fragments per wave");
+        const float floor_v = a.relu ? 0.f : -__builtin_inff();
+        float hb[HNC];
+#pragma unroll
+        for (int c = 0; c < HNC; ++c) hb[c] = a.head_b[c];
+        const int nb = ((lc & 1) ? 4 : 0) + ((lc & 2) ? 2 : 0);
+#pragma unroll
+        for (int c = 0; c < HNC; ++c) {
+            float hs[NF];
+#pragma unroll
+            for (int n = 0; n < NF; ++n) {
+                float sum = 0.f;
+#pragma unroll
+                for (int m = 0; m < 4; ++m)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) relu_fma(sum, acc[m][n][j], floor_v, hw[c][m][j]);
+                hs[n] = sum;
+            }
+            float t[4], u[2];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {  // rows 0, 2: fragment i; rows 1, 3: fragment i + 4
+                const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(hs[i]), __float_as_uint(hs[i + 4]), false, false);
+                t[i] = __uint_as_float(r[0]) + __uint_as_float(r[1]);
+            }
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {  // rows 0, 1: t[j]; rows 2, 3: t[j + 2]
+                const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(t[j]), __float_as_uint(t[j + 2]), false, false);
+                u[j] = __uint_as_float(r[0]) + __uint_as_float(r[1]);
+            }
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int n = nb + j;
+                const int y = y0 + wp * ROWS_W + n / FR;
+                const int x = x0 + (n % FR) * 16 + l15;
+                if (y < aH && x < aW) a.head_out[(((size_t)b * HNC + c) * aH + y) * aW + x] = u[j] + hb[c];
+            }
+        }
+    }
 #pragma unroll
     for (int n = 0; n < NF; ++n) {
         const int y = y0 + wp * ROWS_W + n / FR;
         const int x = x0 + (n % FR) * 16 + l15;
         const bool ok = (y < aH) && (x < aW);
-        if constexpr (HNC > 0) {
-            // fused 1x1 head on the fp32 post-activation values (never rounded to bf16)
-            float hsum[HNC] = {};
-#pragma unroll
-            for (int m = 0; m < 4; ++m)
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const float v = a.relu ? fmaxf(acc[m][n][j], 0.f) : acc[m][n][j];
-#pragma unroll
-                    for (int c = 0; c < HNC; ++c) hsum[c] = fmaf(v, hw[c][m][j], hsum[c]);
-                }
-#pragma unroll
-            for (int c = 0; c < HNC; ++c) {
-                float s = hsum[c];
-                s += __shfl_xor(s, 16);
-                s += __shfl_xor(s, 32);
-                if (ok && lc == 0)
-                    a.head_out[(((size_t)b * HNC + c) * aH + y) * aW + x] = s + a.head_b[c];
-            }
-        }
         if (ok && out_img) {
             char* o = out_img + (size_t)(y * aW + x) * 64;
             if constexpr (PERM) {
