@@ -719,6 +719,10 @@ __global__ __launch_bounds__(256, conv_occupancy(BN, TH, TW)) void conv3x3_mfma_
     static_assert(THP * TWP % 16 == 0, "in-tile must be a whole number of 1-KiB pieces");
     const int aH = a.H, aW = a.W;
     const char* const dma_src = (const char*)a.src0 + (size_t)b * a.H * a.W * a.C0 * sizeof(T);
+    // SRC_DIRECT with C1 > 0: planes >= p0 come from a second full-resolution tensor (the upsampled
+    // half of a concat input, materialised by upsample_kernel when several cout tiles share it)
+    const char* const dma_src1 = MODE == SRC_DIRECT && a.C1 > 0
+                                     ? (const char*)a.src1 + (size_t)b * a.H * a.W * a.C1 * sizeof(T) : nullptr;
     const char* const zero_page = (const char*)a.zero_page;
     // The per-lane source offset of every piece is plane-invariant in the blocked layout.  Where
     // registers allow (direct kernels without the fused head) it is computed once (NPW registers)
@@ -749,7 +753,8 @@ __global__ __launch_bounds__(256, conv_occupancy(BN, TH, TW)) void conv3x3_mfma_
     const unsigned plane_bytes = (unsigned)(aH * aW) * 64u;
     const char* const zero_src = zero_page + ((lane & 3) << 4);
     auto gather_plane_dma = [&](int plane) __attribute__((always_inline)) {
-        const char* const base = dma_src + (size_t)plane * plane_bytes;
+        const char* const base = (MODE == SRC_DIRECT && plane >= p0) ? dma_src1 + (size_t)(plane - p0) * plane_bytes
+                                                                     : dma_src + (size_t)plane * plane_bytes;
         if constexpr (HOIST) {
 #pragma unroll
             for (int jj = 0; jj < NPW; ++jj) {

@@ -95,6 +95,7 @@ struct Plan {
     size_t act_off[NCONV];
     size_t pool_off[4];  // MaxPool2d(2) of x1..x4: kCout[2k+1] channels at level k+1
     size_t scratch_off;
+    size_t up_off[NCONV];  // upsampled half of a concat input, where it is materialised (else unused)
     size_t slab_off;   // split-K partial sums (small problems), kSlabBytes
     size_t total;
 };
@@ -110,6 +111,17 @@ struct Plan {
 struct PlanOpts {
     bool keep_all = false, unfused = false, fused_stem = false, fused_head = false;
 };
+
+// A concat conv whose output spans several 128-cout tiles would bilinearly interpolate every input
+// tile once per cout tile (4x at up1, 2x at up2): there the upsampled half is written to HBM once
+// (upsample_kernel) and gathered by plain LDS-DMA like the skip half.  bf16 only: on the fp32 matrix
+// cores the interpolation is small beside the 16x slower MFMAs, and the tensor twice as big.
+// Small problems (launch-bound, K-split) keep the fused gather: `pixels` = B x H x W at the stage's level.
+inline bool materialise_up(int stage, int precision, bool unfused, long long pixels)
+{
+    return precision == FIUNET_BF16 && !unfused && kMode[stage] == SRC_CONCAT_UP && kCout[stage] >= 256 &&
+           pixels >= 65536;
+}
 
 bool make_plan(int B, int H, int W, int precision, const PlanOpts& o, Plan& p)
 {
@@ -136,6 +148,12 @@ bool make_plan(int B, int H, int W, int precision, const PlanOpts& o, Plan& p)
     for (int k = 0; k < 4; ++k) {  // MaxPool2d(2) of x1..x4: written by conv 2k+1, read by conv 2k+2
         bufs.push_back({align256((size_t)B * p.hs[k + 1] * p.ws[k + 1] * kCout[2 * k + 1] * es), 2 * k + 1,
                         o.keep_all ? END : 2 * k + 2, &p.pool_off[k]});
+    }
+    for (int i = 0; i < NCONV; ++i) {
+        p.up_off[i] = 0;
+        if (materialise_up(i, precision, o.unfused, (long long)B * p.hs[kLevel[i]] * p.ws[kLevel[i]]))
+            bufs.push_back({align256((size_t)B * p.hs[kLevel[i]] * p.ws[kLevel[i]] * kCout[kSrc1[i]] * es), i,
+                            o.keep_all ? END : i, &p.up_off[i]});
     }
     p.scratch_off = 0;
     if (o.unfused)  // ablation path: concat tensor (<= 128 ch at level 0), rewritten by every Up block
@@ -316,7 +334,7 @@ int launch_conv_maybe_split(ConvArgs a, hipStream_t s)
     }
     if constexpr (pair_capable<T, BN, TH, TW, MODE, EPI>()) {
         const long long ntiles = (long long)a.B * ((a.W + TW - 1) / TW) * ((a.H + TH - 1) / TH);
-        if (a.pair && (ntiles + 1) / 2 * (a.Cout / BN) >= 256)
+        if (a.pair && a.C1 == 0 && (ntiles + 1) / 2 * (a.Cout / BN) >= 256)  // (its gather knows one source)
             return launch_pair_cfg<T, BN, TH, TW, EPI>(a, s);
     }
     return launch_conv_cfg<T, BN, TH, TW, MODE, EPI>(a, s);
@@ -497,6 +515,15 @@ int forward_impl(fiunet_ctx* ctx, const float* f1, const float* f2, float* out, 
             hipLaunchKernelGGL((upcat_kernel<T>), dim3(grid_for(n)), dim3(256), 0, s, a, scratch);
             HIP_TRY(hipGetLastError());
             a.src0 = scratch; a.C0 = a.C0 + a.C1; a.C1 = 0; a.src1 = nullptr; mode = SRC_DIRECT;
+        }
+        if (mode == SRC_CONCAT_UP &&
+            materialise_up(i, bf16 ? FIUNET_BF16 : FIUNET_FP32, unfused, (long long)B * a.H * a.W)) {
+            T* up = (T*)(ws + p.up_off[i]);
+            const dim3 grid((unsigned)((a.W * 4 + 255) / 256), (unsigned)a.H, (unsigned)(B * (a.C1 / Elem<T>::PL)));
+            if (grid.y > 65535u || grid.z > 65535u) return fail(FIUNET_ERR_INVALID_ARG, "upsample grid too large");
+            hipLaunchKernelGGL((upsample_kernel<T>), grid, dim3(256), 0, s, a, up);
+            HIP_TRY(hipGetLastError());
+            a.src1 = up; mode = SRC_DIRECT;  // two full-resolution sources: skip planes, then these
         }
         int epi = EPI_PLAIN;
         if (kPoolOut[i] >= 0 && !unfused) {  // also emit MaxPool2d(2) of this output (unet.py:28)

@@ -155,6 +155,21 @@ __global__ __launch_bounds__(256) void upcat_kernel(const ConvArgs a, T* __restr
     }
 }
 
+// The upsampled + padded half of a concat input alone, [B][C1/PL][H][W][PL] (same values as the
+// fused gather: chunk_bilerp).  Used when several cout tiles would each interpolate the same tile.
+template <typename T>
+__global__ __launch_bounds__(256) void upsample_kernel(const ConvArgs a, T* __restrict__ dst)
+{
+    // grid = (chunks of a row / 256, H, B * planes): no per-element division
+    const int p0 = a.C0 / Elem<T>::PL, P1 = a.C1 / Elem<T>::PL;
+    const int i = blockIdx.x * 256 + threadIdx.x;  // (x, 16-B chunk) within the row
+    if (i >= a.W * 4) return;
+    const int y = blockIdx.y;
+    const int b = blockIdx.z / P1, plane = blockIdx.z - b * P1;
+    const uint4 v = gather_chunk<T, SRC_CONCAT_UP>(a, b, y, i >> 2, p0 + plane, i & 3);
+    *reinterpret_cast<uint4*>((char*)dst + (((size_t)blockIdx.z * a.H + y) * a.W * 4 + i) * 16) = v;
+}
+
 // thread = pixel; reads 64 channels, writes nc fp32 planes
 template <typename T>
 __global__ __launch_bounds__(256) void head1x1_kernel(const T* __restrict__ src,
