@@ -129,6 +129,16 @@ __device__ __forceinline__ unsigned pack_bf16x2(float lo, float hi)
     bf16x2 v = {(__bf16)lo, (__bf16)hi};  // v_cvt_pk_bf16_f32, round-to-nearest-even
     return __builtin_bit_cast(unsigned, v);
 }
+// The same conversion spelled as a vector convert: always ONE v_cvt_pk_bf16_f32 (with the SLP
+// vectoriser off, the two scalar casts above sometimes come out as two converts and a v_perm).
+// Not used everywhere: in the fused-head kernels the shorter form lets hipcc hoist all the packs
+// ahead of the head's fp32 math, and spill.
+__device__ __forceinline__ unsigned pack_bf16x2_pk(float lo, float hi)
+{
+    typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+    typedef __attribute__((ext_vector_type(2))) float f32x2;
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2{lo, hi}, bf16x2));
+}
 template <typename T> __device__ __forceinline__ uint4 chunk_pack(const float* f);
 template <> __device__ __forceinline__ uint4 chunk_pack<float>(const float* f)
 {
@@ -1010,51 +1020,56 @@ __global__ __launch_bounds__(256, conv_occupancy(BN, TH, TW)) void conv3x3_mfma_
         if constexpr (MODE == SRC_STEM) {
             // lane group 3 (k = 24..31) reads the row of 1.0s behind the hi image / zeros behind lo
             const int drow = lc < 3 ? lc * PW : PH * PW;
-            // B operands of fragment q (16 in-tile pixels) + where its results go: dst < 0 = lane
-            // beyond the in-tile, bit 30 = pixel outside the image (stores zeros)
-            auto fetch = [&](int q, uint4& bh, uint4& bl, int& dst) __attribute__((always_inline)) {
-                const int i = min(q * 16 + l15, NIN - 1);
-                const int py = i / (TW + 2), px = i - py * (TW + 2);
-                const int e = lc < 3 ? py * PW + px + drow : drow;
-                const unsigned* const sh32 = reinterpret_cast<const unsigned*>(patch) + e;
-                const unsigned* const sl32 = reinterpret_cast<const unsigned*>(patch + PATCH_HALF) + e;
-                bh = make_uint4(sh32[0], sh32[1], sh32[2], sh32[3]);
-                bl = make_uint4(sl32[0], sl32[1], sl32[2], sl32[3]);
-                const int y = y0 - 1 + py, x = x0 - 1 + px;
-                const bool ok = ((unsigned)y < (unsigned)aH) & ((unsigned)x < (unsigned)aW);
-                const int row = py * TWP + px;
-                dst = q * 16 + l15 < NIN ? (row | (ok ? 0 : 1 << 30)) : -1;
+            const unsigned* const ph32 = reinterpret_cast<const unsigned*>(patch);
+            const unsigned* const pl32 = reinterpret_cast<const unsigned*>(patch + PATCH_HALF);
+            // this lane's 8 bytes of a 64-B record for cout tile h = 0 (h = 1: the chunk two further,
+            // i.e. address ^ 32 after the row swizzle, which flips the same bit)
+            const int lane_wr = (lc >> 1) * 16 + (lc & 1) * 8;
+            struct Frag { uint4 bh, bl; int dst; };  // dst < 0: lane beyond the in-tile; bit 30: outside the image
+            // A wave's fragments are 64 in-tile pixels apart: (py, px) advance by constants with one
+            // conditional wrap.  Lanes past the last pixel read a clamped row and store nothing.
+            constexpr int DY = 64 / (TW + 2), DX = 64 % (TW + 2);
+            int py = (wave * 16 + l15) / (TW + 2), px = wave * 16 + l15 - py * (TW + 2);
+            auto fetch = [&](Frag& f) __attribute__((always_inline)) {
+                const int e = lc < 3 ? (int)__umul24(min(py, THP - 1), PW) + px + drow : drow;  // v_mad_u32_u24, not the 64-bit mad
+                f.bh = make_uint4(ph32[e], ph32[e + 1], ph32[e + 2], ph32[e + 3]);
+                f.bl = make_uint4(pl32[e], pl32[e + 1], pl32[e + 2], pl32[e + 3]);
+                const bool ok = ((unsigned)(y0 - 1 + py) < (unsigned)aH) & ((unsigned)(x0 - 1 + px) < (unsigned)aW);
+                f.dst = py < THP ? ((int)__umul24(py, TWP) + px) | (ok ? 0 : 1 << 30) : -1;
+                px += DX; py += DY;
+                if (px >= TW + 2) { px -= TW + 2; py += 1; }
             };
-            uint4 bh, bl;
-            int dst;
-            fetch(wave, bh, bl, dst);
-#pragma unroll 1
-            for (int q = wave; q * 16 < NIN; q += 4) {
-                uint4 nbh, nbl;
-                int ndst;
-                fetch(q + 4, nbh, nbl, ndst);  // next fragment's operands fly during this one's MFMAs
+            auto compute = [&](const Frag& f) __attribute__((always_inline)) {
                 f32x4 s4[2];
 #pragma unroll
                 for (int h = 0; h < 2; ++h) s4[h] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-                for (int h = 0; h < 2; ++h) mma_chunk<T>(s4[h], w.wl[h], bh);
+                for (int h = 0; h < 2; ++h) mma_chunk<T>(s4[h], w.wl[h], f.bh);
 #pragma unroll
-                for (int h = 0; h < 2; ++h) mma_chunk<T>(s4[h], w.wh[h], bl);
+                for (int h = 0; h < 2; ++h) mma_chunk<T>(s4[h], w.wh[h], f.bl);
 #pragma unroll
-                for (int h = 0; h < 2; ++h) mma_chunk<T>(s4[h], w.wh[h], bh);
-                const int row = dst & 0xffff;
-                const bool zero = (dst >> 30) & 1;
+                for (int h = 0; h < 2; ++h) mma_chunk<T>(s4[h], w.wh[h], f.bh);
+                const int row = f.dst & 0xffff;
+                const bool zero = (f.dst >> 30) & 1;
+                const int a0 = row * 64 + (lane_wr ^ (((row >> 2) & 1) << 5));
 #pragma unroll
                 for (int h = 0; h < 2; ++h) {
-                    // channels (h*16 + lc*4 .. +3) of the plane: chunk 2h + (lc>>1), 8-B half lc&1
-                    const int ch = 2 * h + (lc >> 1);
-                    const unsigned p0 = relu_pk_bf16(pack_bf16x2(s4[h][0], s4[h][1]));
-                    const unsigned p1 = relu_pk_bf16(pack_bf16x2(s4[h][2], s4[h][3]));
+                    const unsigned p0 = relu_pk_bf16(pack_bf16x2_pk(s4[h][0], s4[h][1]));
+                    const unsigned p1 = relu_pk_bf16(pack_bf16x2_pk(s4[h][2], s4[h][3]));
                     const uint2 pk = zero ? make_uint2(0u, 0u) : make_uint2(p0, p1);
-                    if (dst >= 0)
-                        *reinterpret_cast<uint2*>(lds_in + row * 64 + ((ch ^ swz(row)) << 4) + (lc & 1) * 8) = pk;
+                    if (f.dst >= 0) *reinterpret_cast<uint2*>(lds_in + (a0 ^ (h * 32))) = pk;
                 }
-                bh = nbh; bl = nbl; dst = ndst;
+            };
+            // two fragments per trip, operands of the next one in flight during the MFMAs of this one
+            constexpr int NQ = (NIN + 15) / 16;
+            Frag fa, fb;
+            fetch(fa);
+#pragma unroll 1
+            for (int q = wave; q < NQ; q += 8) {
+                fetch(fb);
+                compute(fa);
+                fetch(fa);
+                if (q + 4 < NQ) compute(fb);
             }
         }
     };
