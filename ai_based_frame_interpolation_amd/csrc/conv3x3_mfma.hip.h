@@ -622,10 +622,10 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x4 (&acc)[4]
 #pragma unroll
                     for (int h = 0; h < 2; ++h) {
                         const int m = 2 * g + h;
-                        const unsigned a0 = pk_max_i16(pack_bf16x2(acc[m][n][0], acc[m][n][1]),
-                                                       pack_bf16x2(acc[m][n + FR][0], acc[m][n + FR][1]));
-                        const unsigned a1 = pk_max_i16(pack_bf16x2(acc[m][n][2], acc[m][n][3]),
-                                                       pack_bf16x2(acc[m][n + FR][2], acc[m][n + FR][3]));
+                        const unsigned a0 = pk_max_i16(pack_bf16x2_pk(acc[m][n][0], acc[m][n][1]),
+                                                       pack_bf16x2_pk(acc[m][n + FR][0], acc[m][n + FR][1]));
+                        const unsigned a1 = pk_max_i16(pack_bf16x2_pk(acc[m][n][2], acc[m][n][3]),
+                                                       pack_bf16x2_pk(acc[m][n + FR][2], acc[m][n + FR][3]));
                         r[2 * h] = pk_max_i16(a0, dpp_swap_pairs(a0));
                         r[2 * h + 1] = pk_max_i16(a1, dpp_swap_pairs(a1));
                         if (a.relu) { r[2 * h] = relu_pk_bf16(r[2 * h]); r[2 * h + 1] = relu_pk_bf16(r[2 * h + 1]); }
