@@ -519,7 +519,8 @@ int forward_impl(fiunet_ctx* ctx, const float* f1, const float* f2, float* out, 
         if (mode == SRC_CONCAT_UP &&
             materialise_up(i, bf16 ? FIUNET_BF16 : FIUNET_FP32, unfused, (long long)B * a.H * a.W)) {
             T* up = (T*)(ws + p.up_off[i]);
-            const dim3 grid((unsigned)((a.W * 4 + 255) / 256), (unsigned)a.H, (unsigned)(B * (a.C1 / Elem<T>::PL)));
+            const dim3 grid((unsigned)((a.W * 4 + 255) / 256), (unsigned)((a.H + UPS_ROWS - 1) / UPS_ROWS),
+                            (unsigned)(B * (a.C1 / Elem<T>::PL)));
             if (grid.y > 65535u || grid.z > 65535u) return fail(FIUNET_ERR_INVALID_ARG, "upsample grid too large");
             hipLaunchKernelGGL((upsample_kernel<T>), grid, dim3(256), 0, s, a, up);
             HIP_TRY(hipGetLastError());

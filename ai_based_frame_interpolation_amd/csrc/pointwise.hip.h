@@ -157,17 +157,59 @@ __global__ __launch_bounds__(256) void upcat_kernel(const ConvArgs a, T* __restr
 
 // The upsampled + padded half of a concat input alone, [B][C1/PL][H][W][PL] (same values as the
 // fused gather: chunk_bilerp).  Used when several cout tiles would each interpolate the same tile.
+constexpr int UPS_ROWS = 8;  // output rows per thread of upsample_kernel
 template <typename T>
 __global__ __launch_bounds__(256) void upsample_kernel(const ConvArgs a, T* __restrict__ dst)
 {
-    // grid = (chunks of a row / 256, H, B * planes): no per-element division
-    const int p0 = a.C0 / Elem<T>::PL, P1 = a.C1 / Elem<T>::PL;
+    // grid = (chunks of a row / 256, H / UPS_ROWS, B * planes).  A thread owns one (pixel column,
+    // 16-B chunk) and walks UPS_ROWS output rows down it; the row is the same in the whole block,
+    // so the vertical mapping is wave-uniform and the horizontally interpolated source rows are
+    // carried from one output row to the next, exactly like the fused gather's column walk
+    // (chunk_hlerp + chunk_vlerp: the same bits as chunk_bilerp).
+    constexpr int NE = Elem<T>::NE;
+    const int P1 = a.C1 / Elem<T>::PL;
     const int i = blockIdx.x * 256 + threadIdx.x;  // (x, 16-B chunk) within the row
     if (i >= a.W * 4) return;
-    const int y = blockIdx.y;
     const int b = blockIdx.z / P1, plane = blockIdx.z - b * P1;
-    const uint4 v = gather_chunk<T, SRC_CONCAT_UP>(a, b, y, i >> 2, p0 + plane, i & 3);
-    *reinterpret_cast<uint4*>((char*)dst + (((size_t)blockIdx.z * a.H + y) * a.W * 4 + i) * 16) = v;
+    const UpAxis ux = up_axis_x(a, i >> 2);
+    const size_t low_row = (size_t)a.lowW * 64;
+    const char* const col = (const char*)a.src1 + (size_t)b * a.lowH * a.lowW * a.C1 * sizeof(T) +
+                            (size_t)plane * a.lowH * low_row + (i & 3) * 16;
+    const char* const s0 = col + (size_t)ux.i0 * 64;
+    const char* const s1 = col + (size_t)ux.i1 * 64;
+    char* const out = (char*)dst + ((size_t)blockIdx.z * a.H * a.W * 4 + i) * 16;
+    float h0[NE], h1[NE];
+#pragma unroll
+    for (int k = 0; k < NE; ++k) h0[k] = h1[k] = 0.f;
+    int c0 = -1, c1 = -1;  // source rows currently held in h0 / h1 (wave-uniform)
+    const int ybeg = blockIdx.y * UPS_ROWS, yend = min(a.H, ybeg + UPS_ROWS);
+    for (int y = ybeg; y < yend; ++y) {
+        const UpAxis uy = up_axis_y(a, y);
+        uint4 v = make_uint4(0u, 0u, 0u, 0u);
+        if (uy.ok) {
+            if (uy.i0 != c0) {
+                if (uy.i0 == c1) {
+#pragma unroll
+                    for (int k = 0; k < NE; ++k) h0[k] = h1[k];
+                } else {
+                    chunk_hlerp<T>(ldg16(s0 + uy.i0 * low_row), ldg16(s1 + uy.i0 * low_row), ux.h, ux.l, h0);
+                }
+                c0 = uy.i0;
+            }
+            if (uy.i1 != c1) {
+                if (uy.i1 == c0) {
+#pragma unroll
+                    for (int k = 0; k < NE; ++k) h1[k] = h0[k];
+                } else {
+                    chunk_hlerp<T>(ldg16(s0 + uy.i1 * low_row), ldg16(s1 + uy.i1 * low_row), ux.h, ux.l, h1);
+                }
+                c1 = uy.i1;
+            }
+            v = chunk_vlerp<T>(h0, h1, uy.h, uy.l);
+            if (!ux.ok) v = make_uint4(0u, 0u, 0u, 0u);
+        }
+        *reinterpret_cast<uint4*>(out + (size_t)y * a.W * 64) = v;
+    }
 }
 
 // thread = pixel; reads 64 channels, writes nc fp32 planes
