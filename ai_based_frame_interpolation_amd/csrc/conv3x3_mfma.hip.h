@@ -721,6 +721,9 @@ __global__ __launch_bounds__(256, conv_occupancy(BN, TH, TW)) void conv3x3_mfma_
 #pragma unroll
         for (int j = 0; j < NW; ++j) glds16(wsrc + w_src_off[j], dst + j * 1024);
     };
+    // W(0) goes out first (slot 0; slot 1 + spare is the idle staging area for plane 0), ahead of the
+    // in-tile address math below, so its round trip runs under those ~200 instructions
+    issue_w(0);
 
     // ---- in-tile gather (a): planes stored as-is in an NHWC tensor go by LDS-DMA: piece j = 16
     //      consecutive LDS rows (pixels) x 64 B; pixels outside the image and the row-pitch padding
@@ -1093,8 +1096,6 @@ __global__ __launch_bounds__(256, conv_occupancy(BN, TH, TW)) void conv3x3_mfma_
     // diagnostic build (-DFIUNET_STAMP): where does a wave's time go?  [0] total [1] prologue
     // [2] MFMA phases [3] end-of-step wait+barrier [4] plane-boundary gather (rest) [5] epilogue
     // [6] upsample staging DMA + wait [7] upsample interpolation   (s_memtime ticks)
-    // W(0) goes to slot 0, so slot 1 (+ spare) is the idle staging area for plane 0
-    issue_w(0);
     if constexpr (MODE == SRC_STEM) {
         stem_load(stem_w0);
         stage_patch();
