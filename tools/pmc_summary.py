@@ -29,7 +29,8 @@ def load(pass_name):
         d["t"] = (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) * 1e-9
         d[r["Counter_Name"]] = d.get(r["Counter_Name"], 0.0) + float(r["Counter_Value"])
     # keep the LAST complete forward (bench ran NFW = warmup + steps forwards of identical launches)
-    ids = sorted(k for k, v in disp.items() if "fiunet" in v["name"] and ("conv3x3" in v["name"]))
+    ids = sorted(k for k, v in disp.items()
+                 if "fiunet" in v["name"] and ("conv3x3" in v["name"] or "upsample_kernel" in v["name"]))
     per_fw = len(ids) // NFW
     return [disp[i] for i in ids[-per_fw:]]
 
@@ -40,6 +41,8 @@ def short(n):
     if d:  # already demangled (rocprofv3 demangles the float instantiations)
         nums = re.findall(r"\d+", d.group(3))
         return f"conv3x3_{d.group(1)}_kernel<{'f32' if d.group(2) == 'float' else 'bf16'},{','.join(nums)}>"
+    if "upsample_kernel" in n:
+        return "upsample_kernel<" + ("f32" if "<float>" in n or "IfE" in n else "bf16") + ">"
     if not m:
         # rocprofv3 demangles the stem's name oddly; the bench workload is the gray bf16 network
         return "conv3x3_first_kernel<bf16,1>" if "conv3x3_first_kernel" in n else n[:40]
