@@ -22,7 +22,7 @@ LIB_PATH = os.environ.get("FIUNET_LIB") or os.path.join(_PKG, "libfiunet_hip.so"
 CSRC = os.path.join(_PKG, "csrc")
 
 FP32, BF16 = 0, 1
-OPT_UNFUSED, OPT_KEEP_ALL, OPT_PAIR_TILES = 1, 2, 8
+OPT_UNFUSED, OPT_KEEP_ALL, OPT_PAIR_TILES, OPT_GATHER_UPSAMPLE = 1, 2, 8, 16
 
 #: every symbol include/fiunet.h declares (tests/test_abi.py checks the header against this)
 SYMBOLS = (

@@ -109,7 +109,7 @@ struct Plan {
 // read-back) pins every activation to the end; `unfused` adds the ablation path's concat scratch;
 // the fused stem / fused head leave activations 0 / 17 out altogether.
 struct PlanOpts {
-    bool keep_all = false, unfused = false, fused_stem = false, fused_head = false;
+    bool keep_all = false, unfused = false, fused_stem = false, fused_head = false, gather_up = false;
 };
 
 // A concat conv whose output spans several 128-cout tiles would bilinearly interpolate every input
@@ -151,7 +151,7 @@ bool make_plan(int B, int H, int W, int precision, const PlanOpts& o, Plan& p)
     }
     for (int i = 0; i < NCONV; ++i) {
         p.up_off[i] = 0;
-        if (materialise_up(i, precision, o.unfused, (long long)B * p.hs[kLevel[i]] * p.ws[kLevel[i]]))
+        if (materialise_up(i, precision, o.unfused || o.gather_up, (long long)B * p.hs[kLevel[i]] * p.ws[kLevel[i]]))
             bufs.push_back({align256((size_t)B * p.hs[kLevel[i]] * p.ws[kLevel[i]] * kCout[kSrc1[i]] * es), i,
                             o.keep_all ? END : i, &p.up_off[i]});
     }
@@ -359,6 +359,7 @@ PlanOpts plan_opts(const fiunet_ctx* ctx, int H, int W, int precision)
     PlanOpts o;
     o.keep_all = ctx->flags & FIUNET_OPT_KEEP_ALL;
     o.unfused = ctx->flags & FIUNET_OPT_UNFUSED;
+    o.gather_up = ctx->flags & FIUNET_OPT_GATHER_UPSAMPLE;
     // bf16 gray network: the stem is evaluated inside conv 1's gather (SRC_STEM, 16x32 tiles only),
     // unless the ablation path or the debug read-back needs its output in HBM
     o.fused_stem = precision == FIUNET_BF16 && ctx->cf == 1 && !o.unfused && !o.keep_all &&
@@ -517,7 +518,7 @@ int forward_impl(fiunet_ctx* ctx, const float* f1, const float* f2, float* out, 
             a.src0 = scratch; a.C0 = a.C0 + a.C1; a.C1 = 0; a.src1 = nullptr; mode = SRC_DIRECT;
         }
         if (mode == SRC_CONCAT_UP &&
-            materialise_up(i, bf16 ? FIUNET_BF16 : FIUNET_FP32, unfused, (long long)B * a.H * a.W)) {
+            materialise_up(i, bf16 ? FIUNET_BF16 : FIUNET_FP32, unfused || po.gather_up, (long long)B * a.H * a.W)) {
             T* up = (T*)(ws + p.up_off[i]);
             const dim3 grid((unsigned)((a.W * 4 + 255) / 256), (unsigned)((a.H + UPS_ROWS - 1) / UPS_ROWS),
                             (unsigned)(B * (a.C1 / Elem<T>::PL)));

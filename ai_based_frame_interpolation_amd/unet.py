@@ -191,9 +191,11 @@ class FrameInterpolationUNet(nn.Module):
         """Call after editing parameters in place so the next forward re-uploads them."""
         self._ctx_dirty = True
 
-    def set_options(self, *, unfused: bool = False, keep_all: bool = False, pair_tiles: bool = False):
+    def set_options(self, *, unfused: bool = False, keep_all: bool = False, pair_tiles: bool = False,
+                    gather_upsample: bool = False):
         self._options = ((_native.OPT_UNFUSED if unfused else 0) | (_native.OPT_KEEP_ALL if keep_all else 0)
-                         | (_native.OPT_PAIR_TILES if pair_tiles else 0))
+                         | (_native.OPT_PAIR_TILES if pair_tiles else 0)
+                         | (_native.OPT_GATHER_UPSAMPLE if gather_upsample else 0))
         if self._ctx is not None:
             self._ctx.set_options(self._options)
 
@@ -295,7 +297,8 @@ class FrameInterpolationUNet(nn.Module):
         ({tap name: fp32 NCHW tensor}, output)."""
         saved = self._options
         self.set_options(unfused=bool(saved & _native.OPT_UNFUSED), keep_all=True,
-                         pair_tiles=bool(saved & _native.OPT_PAIR_TILES))
+                         pair_tiles=bool(saved & _native.OPT_PAIR_TILES),
+                         gather_upsample=bool(saved & _native.OPT_GATHER_UPSAMPLE))
         try:
             out = self.forward(frame1, frame2)
             b, _, h, w = frame1.shape

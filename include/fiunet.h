@@ -45,8 +45,11 @@ enum fiunet_option {
                                separate kernels instead of fusing them into the consumer conv */
     FIUNET_OPT_KEEP_ALL = 2,/* also store the last 64-ch activation (tap 17) that the fused 1x1
                                head otherwise keeps in registers; for fiunet_debug_read_activation */
-    FIUNET_OPT_PAIR_TILES = 8  /* A/B runs: direct >=128-channel convs on the 8-wave tile-pair kernel
+    FIUNET_OPT_PAIR_TILES = 8, /* A/B runs: direct >=128-channel convs on the 8-wave tile-pair kernel
                                (conv3x3_pair.hip.h: shared weight ring, double-buffered in-tile); same bits */
+    FIUNET_OPT_GATHER_UPSAMPLE = 16 /* A/B runs and tests: always interpolate the upsampled half of a concat
+                               input inside the conv's gather; by default the bf16 convs with >= 2 cout tiles
+                               on >= 64k pixels read it from a tensor written once by upsample_kernel; same bits */
 };
 
 typedef struct fiunet_ctx fiunet_ctx;

@@ -212,3 +212,43 @@ def test_tile_pair_kernel_is_bit_identical(model, dev, prec):
         assert torch.equal(a, bb)
     model.set_options()
     model.precision = "fp32"
+
+
+@pytest.mark.gpu
+def test_materialised_upsample_is_bit_identical_to_the_fused_gather(model, dev, seeded_sd):
+    """bf16 concat convs with >= 2 cout tiles on >= 64k pixels (up2.0 here: 3 x 135 x 240 = 97k) read the
+    upsampled half from a tensor written once by upsample_kernel (two-source direct conv) instead of
+    interpolating it in every cout tile's gather (FIUNET_OPT_GATHER_UPSAMPLE forces the latter): every
+    stage and the output are bit-identical, and the default really took the other kernel."""
+    model.precision = "bf16"
+    f1, f2 = O.make_frames(91, 3, 540, 960)
+    f1, f2 = f1.to(dev), f2.to(dev)
+    try:
+        model.set_options()
+        acts_a, a = model.debug_activations(f1, f2)
+        model._ctx.profile_enable(True)
+        model(f1, f2)
+        torch.cuda.synchronize()
+        _, rows = model._ctx.profile_read()
+        model._ctx.profile_enable(False)
+        names_default = [r[0] for r in rows]
+        model.set_options(gather_upsample=True)
+        acts_b, bb = model.debug_activations(f1, f2)
+        model._ctx.profile_enable(True)
+        model(f1, f2)
+        torch.cuda.synchronize()
+        _, rows = model._ctx.profile_read()
+        model._ctx.profile_enable(False)
+        names_gather = [r[0] for r in rows]
+    finally:
+        model.set_options()
+        model.precision = "fp32"
+    for k in acts_a:
+        assert torch.equal(acts_a[k], acts_b[k]), k
+    assert torch.equal(a, bb)
+    # stage 12 = up2.conv.double_conv.0: template arguments <T, BN, TH, TW, MODE, EPI>, MODE 0 = direct, 2 = concat+upsample
+    assert names_default[12].split(",")[4] == "0" and names_gather[12].split(",")[4] == "2", (names_default[12], names_gather[12])
+    # one frame against the CPU oracle (bf16 contract of the seeded checkpoint)
+    ref = O.unet_forward(seeded_sd, f1[:1].cpu(), f2[:1].cpu())
+    rel = float((a[:1].cpu() - ref).norm() / ref.norm())
+    assert rel <= 2e-2, rel
