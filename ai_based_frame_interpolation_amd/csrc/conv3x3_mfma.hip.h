@@ -40,6 +40,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <type_traits>
 
 namespace fiunet {
 
@@ -79,7 +80,8 @@ struct ConvArgs {
     int lowHg;           //   rows of the WHOLE image's low-res tensor (padT, sy are global too)
     int tilesX, tilesY, nct;
     int relu;
-    const void* zero_page; // >= 64 zero bytes: LDS-DMA source for padding pixels
+    const void* zero_page; // >= 64 zero bytes: padding source of the tile-pair kernel's gather (this kernel zeroes
+                           // the padding slots of its in-tile once and masks those lanes out of the DMAs)
     // SRC_STEM (bf16, gray): the 2->64 stem conv + BN + ReLU (unet.py:72) is evaluated inside the
     // in-tile gather of the NEXT conv, so its 64-channel output never goes to HBM.
     const float* f1;          // frame1 [B][1][H][W] fp32
@@ -331,6 +333,17 @@ __device__ __forceinline__ void glds16(const char* gsrc, unsigned lds_wave_base)
                  "global_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
                  : "=&s"(keep)
                  : "v"(gsrc), "s"(lds_wave_base)
+                 : "memory");
+}
+// The same with a wave-uniform 64-bit base in SGPRs and a 32-bit per-lane byte offset: one VGPR per
+// address instead of two.  Lanes switched off by EXEC neither load nor write their 16 LDS bytes.
+__device__ __forceinline__ void glds16s(const char* sbase, unsigned voff, unsigned lds_wave_base)
+{
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\t"
+                 "global_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(voff), "s"(sbase), "s"(lds_wave_base)
                  : "memory");
 }
 __device__ __forceinline__ void lds_dma_wait_all() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
@@ -706,28 +719,30 @@ __global__ __launch_bounds__(256, conv_occupancy(BN, TH, TW)) void conv3x3_mfma_
     // ---- weight stream: each wave moves NW 1-KiB pieces (16 LDS rows) per step by LDS-DMA.  The
     //      LDS image is lane-linear, so the XOR swizzle goes on the per-lane SOURCE chunk. --------
     constexpr int NW = Tile::W_BYTES / 1024 / 4;
-    int w_src_off[NW];
-#pragma unroll
-    for (int j = 0; j < NW; ++j) {
-        const int lrow = (wave * NW + j) * 16 + (lane >> 2);
-        const int tap = lrow / BN, row = lrow - tap * BN;  // tap = ky within the step
-        w_src_off[j] = (tap * a.Cout + row) * 64 + (((lane & 3) ^ swz(lrow)) << 4);
-    }
+    // Piece j of this wave = packed rows r0 .. r0+15 with r0 = (wave * NW + j) * 16; 16 divides BN, so a
+    // piece lies inside one tap: its source offset is a wave-uniform part (added to the SGPR base) plus
+    // ONE per-lane register shared by all pieces (row within the piece, swizzled 16-B chunk).
+    static_assert(BN % 16 == 0, "a weight piece must not straddle two taps");
+    const unsigned w_lane_off = (unsigned)((lane >> 2) * 64 + (((lane & 3) ^ swz(lane >> 2)) << 4));
     auto issue_w = [&](int step) __attribute__((always_inline)) {  // step counts from this slice's start
         const int lp = step / 3, kx = step - lp * 3, pl = pbeg + lp;
         const char* wsrc = wbase + ((size_t)(pl * 9 + kx * 3) * a.Cout) * 64;  // packed [plane][kx][ky][cout]
         const unsigned dst = __builtin_amdgcn_readfirstlane(
             lds_w_addr + (unsigned)((step & 1) * Tile::W_STRIDE + wave * NW * 1024));
 #pragma unroll
-        for (int j = 0; j < NW; ++j) glds16(wsrc + w_src_off[j], dst + j * 1024);
+        for (int j = 0; j < NW; ++j) {
+            const int r0 = (wave * NW + j) * 16, tap = r0 / BN;  // tap = ky within the step
+            glds16s(wsrc + (size_t)(tap * (a.Cout - BN) + r0) * 64, w_lane_off, dst + j * 1024);
+        }
     };
     // W(0) goes out first (slot 0; slot 1 + spare is the idle staging area for plane 0), ahead of the
     // in-tile address math below, so its round trip runs under those ~200 instructions
     issue_w(0);
 
     // ---- in-tile gather (a): planes stored as-is in an NHWC tensor go by LDS-DMA: piece j = 16
-    //      consecutive LDS rows (pixels) x 64 B; pixels outside the image and the row-pitch padding
-    //      read a 64-byte zero page.  No VGPRs, one memory round trip per plane. -------------------
+    //      consecutive LDS rows (pixels) x 64 B, address = plane base in SGPRs + a 32-bit per-lane
+    //      offset; lanes on pixels outside the image / on the row-pitch padding are switched off
+    //      (their slots were zeroed once).  No data VGPRs, one memory round trip per plane. ---------
     constexpr int NPIECE = THP * TWP / 16;
     static_assert(THP * TWP % 16 == 0, "in-tile must be a whole number of 1-KiB pieces");
     const int aH = a.H, aW = a.W;
@@ -736,13 +751,12 @@ __global__ __launch_bounds__(256, conv_occupancy(BN, TH, TW)) void conv3x3_mfma_
     // half of a concat input, materialised by upsample_kernel when several cout tiles share it)
     const char* const dma_src1 = MODE == SRC_DIRECT && a.C1 > 0
                                      ? (const char*)a.src1 + (size_t)b * a.H * a.W * a.C1 * sizeof(T) : nullptr;
-    const char* const zero_page = (const char*)a.zero_page;
     // The per-lane source offset of every piece is plane-invariant in the blocked layout.  Where
-    // registers allow (direct kernels without the fused head) it is computed once (NPW registers)
-    // and a plane's gather costs ~10 instructions per piece; the concat / head / split-K variants
-    // and the 64-cout tiles (12-14 pieces per wave), which are at the 256-VGPR limit, recompute it
-    // per plane instead (hoisting there spilled, and measured slower).
-    constexpr bool HOIST = (MODE == SRC_DIRECT && HNC == 0 && BN == 128 && EPI != EPI_SPLITK);
+    // registers allow (the plain 128-cout direct kernels) it is computed once (NPW registers, 32-bit)
+    // and a plane's gather costs ~8 instructions per piece; the pooled / concat / head / split-K
+    // variants and the 64-cout tiles (12-14 pieces per wave), which are at the 256-VGPR limit,
+    // rebuild it per plane by the incremental walk below (hoisting there spills).
+    constexpr bool HOIST = (MODE == SRC_DIRECT && BN == 128 && EPI == EPI_PLAIN);
     // Rolling window of in-tile rows across the three ky taps of a step (24 instead of 36 fragment
     // reads per step): bf16 32-wide tiles.  The fp32 instantiations (4 MFMAs per fragment pair keep
     // more operands in flight) and the 16-wide tiles have no registers to spare for the extra row
@@ -764,26 +778,21 @@ __global__ __launch_bounds__(256, conv_occupancy(BN, TH, TW)) void conv3x3_mfma_
         for (int jj = 0; jj < NPW; ++jj) in_off[jj] = piece_off(wave + 4 * jj, 0);
     }
     const unsigned plane_bytes = (unsigned)(aH * aW) * 64u;
-    const char* const zero_src = zero_page + ((lane & 3) << 4);
-    auto gather_plane_dma = [&](int plane) __attribute__((always_inline)) {
-        const char* const base = (MODE == SRC_DIRECT && plane >= p0) ? dma_src1 + (size_t)(plane - p0) * plane_bytes
-                                                                     : dma_src + (size_t)plane * plane_bytes;
+    // Walk over this wave's pieces: f(j, ok, off) with off = byte offset of the lane's 16 B inside a
+    // plane of the source image (valid when ok).  Hoisted kernels read the stored offsets; the others
+    // rebuild them incrementally - a wave's pieces are 64 in-tile pixels apart, so (py, px) and the
+    // linear pixel index advance by constants with one conditional row wrap (adds and compares only;
+    // 64 rows keep the swizzle phase, and NPIECE * 16 == THP * TWP exactly, so py stays inside).
+    auto for_pieces = [&](auto&& f) __attribute__((always_inline)) {
         if constexpr (HOIST) {
 #pragma unroll
             for (int jj = 0; jj < NPW; ++jj) {
                 const int j = wave + 4 * jj;
-                if (j < NPIECE) {
-                    const char* src = in_off[jj] != ~0u ? base + in_off[jj] : zero_src;
-                    glds16(src, __builtin_amdgcn_readfirstlane(lds_in_addr + (unsigned)j * 1024u));
-                }
+                if (j < NPIECE) f(j, in_off[jj] != ~0u, in_off[jj]);
             }
         } else {
             int opq = 0;  // opaque zero: keeps the per-piece address math out of the K loop's
             asm volatile("" : "+s"(opq));  // invariant-hoisting (it would pin a VGPR per piece)
-            // A wave's pieces are 64 in-tile pixels apart: (py, px) and the linear pixel index
-            // advance by constants with one conditional row wrap, so a piece costs adds and
-            // compares only (no division, no multiply); 64 rows keep the swizzle phase, and
-            // NPIECE * 16 == THP * TWP exactly, so py stays inside the in-tile.
             constexpr int DY = 64 / TWP, DX = 64 % TWP;
             const int row0 = wave * 16 + (lane >> 2) + opq;
             int py = row0 / TWP, px = row0 - py * TWP;
@@ -793,12 +802,27 @@ __global__ __launch_bounds__(256, conv_occupancy(BN, TH, TW)) void conv3x3_mfma_
 #pragma unroll 1
             for (int j = wave; j < NPIECE; j += 4) {
                 const bool ok = (px < TW + 2) & ((unsigned)y < (unsigned)aH) & ((unsigned)x < (unsigned)aW);
-                const char* src = ok ? base + lin : zero_src;
-                glds16(src, __builtin_amdgcn_readfirstlane(lds_in_addr + (unsigned)j * 1024u));
+                f(j, ok, lin);
                 px += DX; x += DX; y += DY; lin += dlin;
                 if (px >= TWP) { px -= TWP; x -= TWP; y += 1; lin += dwrap; }
             }
         }
+    };
+    // Padding slots of the in-tile (pixels outside the image, row-pitch filler) are the same for every
+    // plane of the tile: they are zeroed ONCE here, and the per-plane DMAs simply leave those lanes
+    // switched off (the interpolated planes of a concat conv write zeros there themselves).
+    if constexpr (MODE != SRC_STEM) {
+        for_pieces([&](int j, bool ok, unsigned) __attribute__((always_inline)) {
+            if (!ok) *reinterpret_cast<uint4*>(lds_in + j * 1024 + lane * 16) = make_uint4(0u, 0u, 0u, 0u);
+        });
+    }
+    auto gather_plane_dma = [&](int plane) __attribute__((always_inline)) {
+        // wave-uniform plane base in SGPRs + the lane's 32-bit offset
+        const char* const base = (MODE == SRC_DIRECT && plane >= p0) ? dma_src1 + (size_t)(plane - p0) * plane_bytes
+                                                                     : dma_src + (size_t)plane * plane_bytes;
+        for_pieces([&](int j, bool ok, unsigned off) __attribute__((always_inline)) {
+            if (ok) glds16s(base, off, __builtin_amdgcn_readfirstlane(lds_in_addr + (unsigned)j * 1024u));
+        });
     };
 
 #ifdef FIUNET_STAMP
@@ -1116,6 +1140,18 @@ __global__ __launch_bounds__(256, conv_occupancy(BN, TH, TW)) void conv3x3_mfma_
             const char* wcur = lds_w + (step & 1) * Tile::W_STRIDE + a_off;
             // this wave's in-tile rows 0 .. ROWS_W+1 at column offset kx: row i serves tap ky for the
             // output row i - ky, so every fragment is read once and used by up to three taps
+            // Last step of a plane whose successor arrives by plain LDS-DMA: after the load of the last
+            // in-tile row (tap ky = 1) the rolling window holds everything the rest of the step needs,
+            // so a barrier there declares the in-tile dead and the next plane's DMA is issued BEFORE
+            // the remaining 64 MFMAs, which cover its round trip (no second in-tile buffer needed).
+#ifndef FIUNET_NO_EARLY_GATHER
+            constexpr bool EARLY_OK = ROLL && MODE == SRC_DIRECT;  // (the concat kernels would spill 6-8 registers)
+#else
+            constexpr bool EARLY_OK = false;
+#endif
+            bool early = false;
+            if constexpr (EARLY_OK)
+                early = kx == 2 && plane + 1 < pend && (MODE == SRC_DIRECT || plane + 1 < p0);
             if constexpr (ROLL) {
                 uint4 xb[ROWS_W + 2][FR];
                 auto load_row = [&](int i) __attribute__((always_inline)) {
@@ -1132,6 +1168,13 @@ __global__ __launch_bounds__(256, conv_occupancy(BN, TH, TW)) void conv3x3_mfma_
                     for (int m = 0; m < 4; ++m)
                         wa[m] = *reinterpret_cast<const uint4*>(wcur + (ky * BN + m * 16) * 64);
                     if (ky < 2) load_row(ROWS_W + ky);  // the one new row of the next tap (row ky dies after this one)
+                    if (ky == 1 && early) {
+                        // that was this wave's last read of the plane's in-tile (rows 1 .. ROWS_W+1 are
+                        // in registers): once every wave is here the in-tile is dead and the next
+                        // plane's DMA goes out, 64 MFMAs ahead of the boundary
+                        __syncthreads();
+                        gather_plane(plane + 1, step & 1, false);
+                    }
 #pragma unroll
                     for (int m = 0; m < 4; ++m)
 #pragma unroll
@@ -1171,7 +1214,7 @@ __global__ __launch_bounds__(256, conv_occupancy(BN, TH, TW)) void conv3x3_mfma_
             __builtin_amdgcn_sched_barrier(0);
 #endif
             STAMP(2);
-            if (kx == 2 && plane + 1 < pend) {
+            if (kx == 2 && plane + 1 < pend && !early) {
                 __syncthreads();  // every wave is done with this plane's in-tile and with W(step)
                 gather_plane(plane + 1, step & 1, false);
                 lds_dma_wait_all();
