@@ -783,6 +783,24 @@ __global__ __launch_bounds__(256, conv_occupancy(BN, TH, TW)) void conv3x3_mfma_
     // rebuild them incrementally - a wave's pieces are 64 in-tile pixels apart, so (py, px) and the
     // linear pixel index advance by constants with one conditional row wrap (adds and compares only;
     // 64 rows keep the swizzle phase, and NPIECE * 16 == THP * TWP exactly, so py stays inside).
+    // Non-hoisted kernels keep THREE registers instead of one per piece: the first piece's offset and
+    // two bit masks (piece jj valid / row wrap after piece jj), filled once per tile by the walk.
+    unsigned pm_lin0 = 0, pm_valid = 0, pm_wrap = 0;
+    constexpr int PM_DY = 64 / TWP, PM_DX = 64 % TWP;
+    const unsigned pm_dlin = (unsigned)(PM_DY * aW + PM_DX) * 64u, pm_dwrap = (unsigned)(aW - TWP) * 64u;
+    if constexpr (!HOIST && MODE != SRC_STEM) {
+        const int row0 = wave * 16 + (lane >> 2);
+        int py = row0 / TWP, px = row0 - py * TWP;
+        int y = y0 - 1 + py, x = x0 - 1 + px;
+        pm_lin0 = (unsigned)(y * aW + x) * 64u + (((lane & 3) ^ swz(row0)) << 4);
+#pragma unroll
+        for (int jj = 0; jj < NPW; ++jj) {
+            const bool ok = (px < TW + 2) & ((unsigned)y < (unsigned)aH) & ((unsigned)x < (unsigned)aW);
+            pm_valid |= (ok ? 1u : 0u) << jj;
+            px += PM_DX; x += PM_DX; y += PM_DY;
+            if (px >= TWP) { px -= TWP; x -= TWP; y += 1; pm_wrap |= 1u << jj; }
+        }
+    }
     auto for_pieces = [&](auto&& f) __attribute__((always_inline)) {
         if constexpr (HOIST) {
 #pragma unroll
@@ -791,20 +809,16 @@ __global__ __launch_bounds__(256, conv_occupancy(BN, TH, TW)) void conv3x3_mfma_
                 if (j < NPIECE) f(j, in_off[jj] != ~0u, in_off[jj]);
             }
         } else {
-            int opq = 0;  // opaque zero: keeps the per-piece address math out of the K loop's
-            asm volatile("" : "+s"(opq));  // invariant-hoisting (it would pin a VGPR per piece)
-            constexpr int DY = 64 / TWP, DX = 64 % TWP;
-            const int row0 = wave * 16 + (lane >> 2) + opq;
-            int py = row0 / TWP, px = row0 - py * TWP;
-            int y = y0 - 1 + py, x = x0 - 1 + px;
-            unsigned lin = (unsigned)(y * aW + x) * 64u + (((lane & 3) ^ swz(row0)) << 4);
-            const unsigned dlin = (unsigned)(DY * aW + DX) * 64u, dwrap = (unsigned)(aW - TWP) * 64u;
-#pragma unroll 1
-            for (int j = wave; j < NPIECE; j += 4) {
-                const bool ok = (px < TW + 2) & ((unsigned)y < (unsigned)aH) & ((unsigned)x < (unsigned)aW);
-                f(j, ok, lin);
-                px += DX; x += DX; y += DY; lin += dlin;
-                if (px >= TWP) { px -= TWP; x -= TWP; y += 1; lin += dwrap; }
+            // opaque copies: without them hipcc hoists every piece's offset and mask out of the K loop
+            // (they are plane-invariant), i.e. rebuilds the hoisted form and spills
+            unsigned lin = pm_lin0, valid = pm_valid, wrap = pm_wrap;
+            asm volatile("" : "+v"(lin), "+v"(valid), "+v"(wrap));
+#pragma unroll
+            for (int jj = 0; jj < NPW; ++jj) {
+                const int j = wave + 4 * jj;
+                if (j < NPIECE) f(j, ((valid >> jj) & 1u) != 0u, lin);
+                // (pm_dwrap is negative mod 2^32 when the level is narrower than the in-tile pitch)
+                lin += pm_dlin + (((wrap >> jj) & 1u) ? pm_dwrap : 0u);
             }
         }
     };
