@@ -755,7 +755,7 @@ __global__ __launch_bounds__(256, conv_occupancy(BN, TH, TW)) void conv3x3_mfma_
     // registers allow (the plain 128-cout direct kernels) it is computed once (NPW registers, 32-bit)
     // and a plane's gather costs ~8 instructions per piece; the pooled / concat / head / split-K
     // variants and the 64-cout tiles (12-14 pieces per wave), which are at the 256-VGPR limit,
-    // rebuild it per plane by the incremental walk below (hoisting there spills).
+    // rebuild it per plane from three registers (see pm_* below; hoisting there spills).
     constexpr bool HOIST = (MODE == SRC_DIRECT && BN == 128 && EPI == EPI_PLAIN);
     // Rolling window of in-tile rows across the three ky taps of a step (24 instead of 36 fragment
     // reads per step): bf16 32-wide tiles.  The fp32 instantiations (4 MFMAs per fragment pair keep
@@ -768,8 +768,8 @@ __global__ __launch_bounds__(256, conv_occupancy(BN, TH, TW)) void conv3x3_mfma_
         const int py = row / TWP, px = row - py * TWP;
         const int y = y0 - 1 + py, x = x0 - 1 + px;
         const bool ok = (px < TW + 2) & (py < THP) & (y >= 0) & (y < aH) & (x >= 0) & (x < aW);
-        // one image is < 4 GiB, so a 32-bit byte offset from the batch base is enough;
-        // ~0u marks padding (reads the zero page)
+        // one image plane is < 4 GiB, so a 32-bit byte offset from the plane base is enough;
+        // ~0u marks padding (lane switched off, slot zeroed once)
         return ok ? (unsigned)(y * aW + x) * 64u + (((lane & 3) ^ swz(row)) << 4) : ~0u;
     };
     unsigned in_off[HOIST ? NPW : 1];
@@ -779,12 +779,12 @@ __global__ __launch_bounds__(256, conv_occupancy(BN, TH, TW)) void conv3x3_mfma_
     }
     const unsigned plane_bytes = (unsigned)(aH * aW) * 64u;
     // Walk over this wave's pieces: f(j, ok, off) with off = byte offset of the lane's 16 B inside a
-    // plane of the source image (valid when ok).  Hoisted kernels read the stored offsets; the others
-    // rebuild them incrementally - a wave's pieces are 64 in-tile pixels apart, so (py, px) and the
-    // linear pixel index advance by constants with one conditional row wrap (adds and compares only;
-    // 64 rows keep the swizzle phase, and NPIECE * 16 == THP * TWP exactly, so py stays inside).
-    // Non-hoisted kernels keep THREE registers instead of one per piece: the first piece's offset and
-    // two bit masks (piece jj valid / row wrap after piece jj), filled once per tile by the walk.
+    // plane of the source image (valid when ok).  Hoisted kernels read the stored offsets.  The others
+    // keep THREE registers instead of one per piece: a wave's pieces are 64 in-tile pixels apart, so
+    // (py, px) and the linear pixel index advance by constants with one conditional row wrap (64 rows
+    // keep the swizzle phase; NPIECE * 16 == THP * TWP exactly, so py stays inside) - the walk is done
+    // once per tile and leaves the first piece's offset plus two bit masks (piece jj valid / row wrap
+    // after piece jj); a plane's gather then needs no coordinate arithmetic at all.
     unsigned pm_lin0 = 0, pm_valid = 0, pm_wrap = 0;
     constexpr int PM_DY = 64 / TWP, PM_DX = 64 % TWP;
     const unsigned pm_dlin = (unsigned)(PM_DY * aW + PM_DX) * 64u, pm_dwrap = (unsigned)(aW - TWP) * 64u;
