@@ -5,9 +5,12 @@ middle frame with each method, turn it into the uint8 image `postprocess_image` 
 data_range 255: metrics.py).  The reference does the scoring on the host, one frame at a time.
 
 Methods: "unet" (the HIP forward, `forward_u8`) and "linear" ((f0 + f1) / 2 on the [-1, 1] tensors,
-evaluation_simple.py:71-74).  The reference's third method, Farneback optical flow
-(evaluation_simple.py:76-103), is OpenCV code and OpenCV is not in this image: asking for it raises.
-Statistics per method follow evaluation_simple.py:226-242 (numpy mean / population std / min / max).
+evaluation_simple.py:71-74).  The reference's third method, "optical_flow" (evaluation_simple.py:76-103),
+IS OpenCV: `cv2.calcOpticalFlowFarneback` + `cv2.remap`.  It is not restated here (nothing in this
+image could pin a restatement of Farneback); when `cv2` is importable the method calls OpenCV itself on
+the host with the reference's parameters and only the scoring runs on the device, otherwise asking for
+it raises.  Statistics per method follow evaluation_simple.py:226-242 (numpy mean / population std /
+min / max).
 """
 from __future__ import annotations
 
@@ -18,7 +21,35 @@ import torch
 
 from . import _native, metrics
 
-METHODS = ("unet", "linear")
+METHODS = ("unet", "linear")          # always available
+ALL_METHODS = METHODS + ("optical_flow",)  # the third one needs OpenCV
+
+
+def _optical_flow_u8(f0: torch.Tensor, f1: torch.Tensor) -> torch.Tensor:
+    """optical_flow_interpolation_baseline (evaluation_simple.py:76-103) through OpenCV itself, frame by
+    frame on the host: Farneback flow f0 -> f1 (pyr_scale 0.5, 3 levels, winsize 15, 3 iterations,
+    poly_n 5, poly_sigma 1.1), frame 0 sampled at (x, y) + flow/2 clipped to the image, bilinear,
+    replicated border.  uint8 [N,1,H,W] in, uint8 [N,1,H,W] on the same device out."""
+    try:
+        import cv2  # type: ignore
+    except ImportError as e:
+        raise NotImplementedError("the optical-flow baseline is OpenCV's Farneback + remap "
+                                  "(evaluation_simple.py:76-103); OpenCV is not available here") from e
+    if f0.shape[1] != 1:
+        raise RuntimeError("the optical-flow baseline is defined on grayscale frames (one channel)")
+    a_all, b_all = f0[:, 0].cpu().numpy(), f1[:, 0].cpu().numpy()
+    out = np.empty_like(a_all)
+    for i in range(a_all.shape[0]):
+        a, b = np.ascontiguousarray(a_all[i]), np.ascontiguousarray(b_all[i])
+        flow = cv2.calcOpticalFlowFarneback(a, b, None, pyr_scale=0.5, levels=3, winsize=15, iterations=3,
+                                            poly_n=5, poly_sigma=1.1, flags=0)
+        half = flow * 0.5
+        h, w = a.shape
+        ys, xs = np.mgrid[0:h, 0:w].astype(np.float32)
+        new_x = np.clip(xs + half[:, :, 0], 0, w - 1)
+        new_y = np.clip(ys + half[:, :, 1], 0, h - 1)
+        out[i] = cv2.remap(a, new_x, new_y, cv2.INTER_LINEAR, borderMode=cv2.BORDER_REPLICATE)
+    return torch.from_numpy(out).unsqueeze(1).to(f0.device)
 
 
 def _linear_u8(f0: torch.Tensor, f1: torch.Tensor) -> torch.Tensor:
@@ -41,11 +72,14 @@ def evaluate_triplets(model, frame_t0: torch.Tensor, frame_t1: torch.Tensor, gro
     average_ssim, std_*, min_*, max_*}}, 'per_triplet': {m: {'psnr': ndarray, 'ssim': ndarray}}}."""
     methods = tuple(methods)
     for m in methods:
-        if m == "optical_flow":
-            raise NotImplementedError("the optical-flow baseline is OpenCV's Farneback "
-                                      "(evaluation_simple.py:76-103); OpenCV is not available here")
-        if m not in METHODS:
-            raise ValueError(f"unknown method {m!r}; choose from {METHODS}")
+        if m not in ALL_METHODS:
+            raise ValueError(f"unknown method {m!r}; choose from {ALL_METHODS}")
+    if "optical_flow" in methods:
+        try:
+            import cv2  # noqa: F401
+        except ImportError as e:
+            raise NotImplementedError("the optical-flow baseline is OpenCV's Farneback + remap "
+                                      "(evaluation_simple.py:76-103); OpenCV is not available here") from e
     if not (frame_t0.shape == frame_t1.shape == ground_truth.shape) or frame_t0.dim() != 4:
         raise RuntimeError("expected three uint8 [N, C, H, W] tensors of equal shape")
     n = frame_t0.shape[0]
@@ -54,7 +88,8 @@ def evaluate_triplets(model, frame_t0: torch.Tensor, frame_t1: torch.Tensor, gro
         e = min(s + batch, n)
         f0, f1, gt = frame_t0[s:e], frame_t1[s:e], ground_truth[s:e]
         for m in methods:
-            pred = model.forward_u8(f0, f1) if m == "unet" else _linear_u8(f0, f1)
+            pred = (model.forward_u8(f0, f1) if m == "unet" else
+                    _linear_u8(f0, f1) if m == "linear" else _optical_flow_u8(f0, f1))
             # one value per frame: channels (RGB variant) are averaged, as skimage's channel_axis does
             per[m]["psnr"].append(_frame_psnr(pred, gt))
             per[m]["ssim"].append(metrics.ssim_u8(pred, gt).mean(dim=1))

@@ -217,3 +217,45 @@ def test_image_file_io_without_opencv(tmp_path):
     with pytest.raises(ValueError, match="Could not read image"):
         (tmp_path / "bad.png").write_bytes(b"not a png")
         P.preprocess_image(str(tmp_path / "bad.png"))
+
+
+def test_optical_flow_baseline_delegates_to_opencv_with_the_reference_parameters(monkeypatch):
+    """evaluation_simple.py:76-103: Farneback(f0, f1, pyr_scale 0.5, levels 3, winsize 15, iterations 3,
+    poly_n 5, poly_sigma 1.1, flags 0), then frame 0 remapped at grid + flow/2 (clipped), INTER_LINEAR,
+    BORDER_REPLICATE.  OpenCV is not installed here, so a recording stand-in checks the call contract."""
+    import sys
+    import types
+    from ai_based_frame_interpolation_amd import evaluation
+
+    calls = {}
+    fake = types.ModuleType("cv2")
+    fake.INTER_LINEAR, fake.BORDER_REPLICATE = 1, 1
+
+    def farneback(a, b, flow, **kw):
+        calls["farneback"] = (a.copy(), b.copy(), flow, kw)
+        f = np.zeros(a.shape + (2,), dtype=np.float32)
+        f[..., 0], f[..., 1] = 4.0, -2.0        # 4 px right, 2 px up
+        return f
+
+    def remap(src, mx, my, interp, borderMode=None):
+        calls["remap"] = (mx.copy(), my.copy(), interp, borderMode)
+        return src[np.rint(my).astype(int), np.rint(mx).astype(int)]
+
+    fake.calcOpticalFlowFarneback, fake.remap = farneback, remap
+    monkeypatch.setitem(sys.modules, "cv2", fake)
+    g = torch.Generator().manual_seed(3)
+    f0 = torch.randint(0, 256, (2, 1, 12, 20), dtype=torch.uint8, generator=g)
+    f1 = torch.randint(0, 256, (2, 1, 12, 20), dtype=torch.uint8, generator=g)
+    out = evaluation._optical_flow_u8(f0, f1)
+    assert out.shape == f0.shape and out.dtype == torch.uint8
+    a, b, flow, kw = calls["farneback"]
+    assert flow is None and np.array_equal(a, f0[1, 0].numpy()) and np.array_equal(b, f1[1, 0].numpy())
+    assert kw == dict(pyr_scale=0.5, levels=3, winsize=15, iterations=3, poly_n=5, poly_sigma=1.1, flags=0)
+    mx, my, interp, border = calls["remap"]
+    ys, xs = np.mgrid[0:12, 0:20].astype(np.float32)
+    assert np.array_equal(mx, np.clip(xs + 2.0, 0, 19)) and np.array_equal(my, np.clip(ys - 1.0, 0, 11))
+    assert interp == fake.INTER_LINEAR and border == fake.BORDER_REPLICATE
+    exp = f0[1, 0].numpy()[np.clip(np.arange(12) - 1, 0, 11)][:, np.clip(np.arange(20) + 2, 0, 19)]
+    assert np.array_equal(out[1, 0].numpy(), exp)
+    with pytest.raises(RuntimeError, match="grayscale"):
+        evaluation._optical_flow_u8(f0.repeat(1, 3, 1, 1), f1.repeat(1, 3, 1, 1))
