@@ -156,13 +156,13 @@ def test_psnr_within_0p05_db_of_cpu_reference(dev, h, w):
     ref_u8 = O.postprocess_tensor(O.unet_forward(sd, fa, fc))
     psnr_cpu = O.psnr_u8(truth.numpy(), ref_u8)
     assert psnr_cpu >= 30.0, psnr_cpu
-    # fp32 path: the north-star bound.  bf16 path: its error is small (>= 55 dB from the CPU frame)
-    # but gain-like, hence correlated with this checkpoint's own deep-network term, which is what
-    # separates the output from the truth; measured 0.02-0.07 dB depending on the size and on how
-    # the weights happen to round (0.067 dB at 256x256, 0.062 dB at 1080p with BatchNorm's scale
-    # folded into the bf16 weights), i.e. it MISSES the 0.05 dB bound by up to 0.02 dB on this
-    # checkpoint; asserted here at 0.10 dB.
-    for prec, bound in (("fp32", 0.05), ("bf16", 0.10)):
+    # fp32 path: 0.0000 dB.  bf16 path: its error is small (>= 55 dB from the CPU frame) but partly
+    # systematic - fixed rounding errors of the weights give every channel a small gain / offset error,
+    # which correlates with this checkpoint's own deep-network term, the thing that separates the output
+    # from the truth.  With round-to-nearest weights it measured 0.04-0.07 dB (a miss); with the
+    # error-feedback rounding of the filter weights (fiunet.hip: f32_to_bf16_feedback) 0.025-0.048 dB
+    # over five scenes and three sizes: inside the north-star bound.
+    for prec, bound in (("fp32", 0.05), ("bf16", 0.05)):
         m.precision = prec
         hip_u8 = m.forward_u8(a[None, None].to(dev), c[None, None].to(dev))[0, 0].cpu().numpy()
         psnr_hip = O.psnr_u8(truth.numpy(), hip_u8)
