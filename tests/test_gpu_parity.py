@@ -333,5 +333,5 @@ def test_random_shapes_fp32_and_bf16_vs_oracle(model, dev, seeded_sd):
         model.precision = "bf16"
         out = model(f1.to(dev), f2.to(dev)).cpu()
         rel = ((out - ref).norm() / ref.norm()).item()
-        assert rel <= 2.5e-2 and torch.isfinite(out).all(), (b, h, w, rel)
+        assert rel <= 2e-2 and torch.isfinite(out).all(), (b, h, w, rel)  # worst of a 45-shape sweep: 1.04e-2
     model.precision = "fp32"
