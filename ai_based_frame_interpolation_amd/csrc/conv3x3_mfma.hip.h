@@ -786,6 +786,7 @@ __global__ __launch_bounds__(256, conv_occupancy(BN, TH, TW)) void conv3x3_mfma_
     // once per tile and leaves the first piece's offset plus two bit masks (piece jj valid / row wrap
     // after piece jj); a plane's gather then needs no coordinate arithmetic at all.
     unsigned pm_lin0 = 0, pm_valid = 0, pm_wrap = 0;
+    static_assert(NPW <= 32, "one mask bit per piece of a wave");
     constexpr int PM_DY = 64 / TWP, PM_DX = 64 % TWP;
     const unsigned pm_dlin = (unsigned)(PM_DY * aW + PM_DX) * 64u, pm_dwrap = (unsigned)(aW - TWP) * 64u;
     if constexpr (!HOIST && MODE != SRC_STEM) {
