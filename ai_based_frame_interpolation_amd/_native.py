@@ -23,6 +23,7 @@ CSRC = os.path.join(_PKG, "csrc")
 
 FP32, BF16 = 0, 1
 OPT_UNFUSED, OPT_KEEP_ALL, OPT_PAIR_TILES, OPT_GATHER_UPSAMPLE = 1, 2, 8, 16
+OPT_RNE_WEIGHTS, OPT_NO_DITHER = 32, 64
 
 #: every symbol include/fiunet.h declares (tests/test_abi.py checks the header against this)
 SYMBOLS = (
@@ -32,6 +33,7 @@ SYMBOLS = (
     "fiunet_workspace_bytes_u8", "fiunet_forward_u8", "fiunet_preprocess_u8",
     "fiunet_postprocess_u8", "fiunet_debug_read_activation", "fiunet_profile_enable",
     "fiunet_profile_read", "fiunet_metrics_workspace_bytes", "fiunet_psnr_u8", "fiunet_ssim_u8",
+    "fiunet_ssim_gauss_workspace_bytes", "fiunet_ssim_gauss_f32",
 )
 
 _lib = None
@@ -80,6 +82,9 @@ def lib() -> ctypes.CDLL:
     L.fiunet_metrics_workspace_bytes.restype = sz
     L.fiunet_psnr_u8.argtypes = [vp, vp, ci, ci, ci, vp, vp, sz, vp]
     L.fiunet_ssim_u8.argtypes = [vp, vp, ci, ci, ci, vp, vp, sz, vp]
+    L.fiunet_ssim_gauss_workspace_bytes.argtypes = [ci, ci, ci]
+    L.fiunet_ssim_gauss_workspace_bytes.restype = sz
+    L.fiunet_ssim_gauss_f32.argtypes = [vp, vp, ci, ci, ci, ci, vp, vp, vp, sz, vp]
     L.fiunet_profile_enable.argtypes = [vp, ci]
     L.fiunet_profile_read.argtypes = [vp, ctypes.POINTER(ci), ctypes.POINTER(ctypes.c_float),
                                       ctypes.POINTER(ctypes.c_double), ctypes.c_char_p, ci]

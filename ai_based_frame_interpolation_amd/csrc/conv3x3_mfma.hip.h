@@ -86,8 +86,10 @@ struct ConvArgs {
     // in-tile gather of the NEXT conv, so its 64-channel output never goes to HBM.
     const float* f1;          // frame1 [B][1][H][W] fp32
     const float* f2;          // frame2
-    const void* stem_w;       // [2 (hi, lo)][64 couts][32 k] bf16 of w * bn_scale; k = dy*8 + dx*2 + frame, zero for
-                              // dx = 3 or dy = 3 except k = 24, which holds the BatchNorm shift (its operand is 1.0)
+    const void* stem_w;       // [2 (hi, lo)][64 packed rows][32 k] bf16 of w * bn_scale; k = lane group*8 + dx*2 + frame
+                              // with lane groups 0, 1, 2 <-> dy = 0, 2, 1; zero for dx = 3; k = 24 (lane group 3) holds
+                              // the BatchNorm shift (its operand is 1.0); packed row R <-> cout bf16_row_to_cout(R)
+    float dither;             // bf16 stem only: amplitude of the ordered input dither (stem_dither), 0 = off
     // EPI_SPLITK: the K loop (planes) is cut into `ksplit` slices handled by different workgroups;
     // slice s stores its raw fp32 partial sums to kslab[s][B*H*W][Cout]; splitk_finalize_kernel adds
     // the slices in order (deterministic) and applies scale/shift/ReLU.
@@ -233,6 +235,30 @@ __device__ __forceinline__ uint4 chunk_vlerp(const float* top, const float* bot,
 }
 
 __device__ __forceinline__ uint4 ldg16(const char* p) { return *reinterpret_cast<const uint4*>(p); }
+
+// Ordered dither of the bf16 path's INPUT (bf16 stem only; the fp32 path never sees it).
+// Why: a bf16 activation has 8 significant bits, the frames have 8 too (x = 2*u8/255 - 1), and a network
+// that interpolates carries the frames themselves through the full-resolution skip (x1 -> up4).  Rounded
+// to nearest, the error of such a carried value is a fixed sawtooth of the pixel's intensity, i.e. a
+// small intensity-dependent gain/offset error that is the same in every smooth region of the image: it
+// correlates with the content and moves PSNR-vs-truth by 0.03-0.05 dB on an interpolating checkpoint,
+// ten times what its energy alone would (tools/bf16_emulate.py isolates it: rounding the stem output /
+// x1 / up4.0 accounts for nearly all of the bf16 path's PSNR difference; all other layers together for
+// < 0.01 dB).  The classic remedy is dither: frame 1 gets +d(y, x), frame 2 gets -d(y, x) before the
+// stem conv, d = the 8x8 Bayer matrix scaled to a quarter of an 8-bit input step peak-to-peak/2
+// (amplitude 2^-8 = +-2^-9, below the frames' own quantisation noise).  The rounding error of a carried
+// value then averages to zero over every 8x8 block whatever the intensity, and in the blend
+// 0.5*(f1 + f2) the two dithers cancel exactly.  Measured (emulation, 5 checkpoints x 5 scenes):
+// |PSNR_bf16 - PSNR_fp32| 0.017-0.039 dB -> <= 0.0125 dB, rel-L2 of the output error slightly lower.
+// Deterministic and position-based: (y & 7, x & 7) of the GLOBAL pixel (strip origins are multiples of
+// 16 rows), so tiled == un-tiled and batch invariance are unaffected.
+__device__ __forceinline__ float stem_dither(int y, int x)
+{
+    // Bayer index matrix M8: bits of (x ^ y) and y interleaved, bit 0 most significant
+    const unsigned a = (unsigned)(x ^ y) & 7u, b = (unsigned)y & 7u;
+    const unsigned m = ((a & 1u) << 5) | ((b & 1u) << 4) | ((a & 2u) << 2) | ((b & 2u) << 1) | ((a & 4u) >> 1) | ((b & 4u) >> 2);
+    return ((float)m + 0.5f) * (1.0f / 64.0f) - 0.5f;  // (-0.5, 0.5), 64 levels, zero mean over a period
+}
 
 // Bilinear x2 (align_corners=True) source coordinates and weights of one upsampled+padded pixel
 // (unet.py:40,49-53), shared by every kernel that upsamples so they agree bit for bit.
@@ -412,11 +438,18 @@ template <int BN, int TH, int TW, int MODE> struct ConvTile {
     static constexpr int SPARE_BYTES =
         (MODE == SRC_CONCAT_UP && LR_PIECES * 1024 > W_BYTES) ? LR_PIECES * 1024 - W_BYTES : 0;
     static constexpr int W_STRIDE = W_BYTES + SPARE_BYTES;  // slot 1 = slot 0 + W_STRIDE
-    // SRC_STEM: raw fp32 patch of both frames, (TH+4) x (TW+4) pixels, after the ring
-    static constexpr int PATCH_W = TW + 4, PATCH_H = TH + 4;
+    // SRC_STEM: raw patch of both frames, (TH+4) x (TW+4) pixels, after the ring.  Row pitch PATCH_W
+    // pixels (= dwords) with 2 * PATCH_W = 16 (mod 32): the fragment reads are ds_read2_b32 (32 banks,
+    // lanes 0-31 together), lane groups 0 / 1 read patch rows py / py+2, so their 16 dwords each land in
+    // complementary bank halves (a pitch of TW+4 = 36 made them overlap in 8 banks: 2-way conflicts)
+    static constexpr int PATCH_W = TW + 8, PATCH_H = TH + 4;
+    static_assert(MODE != SRC_STEM || (2 * PATCH_W) % 32 == 16, "patch pitch: lane groups 0/1 must not share banks");
     static constexpr int PATCH_OFF = IN_BYTES + 2 * W_BYTES + SPARE_BYTES;
-    // two bf16 images (hi, lo) of [PATCH_H][PATCH_W][2 frames] + 64 B of zero pad each
-    static constexpr int PATCH_BYTES = MODE == SRC_STEM ? 2 * (PATCH_H * PATCH_W * 4 + 64) : 0;
+    // two bf16 images (hi, lo) of [PATCH_H][PATCH_W][2 frames], each followed by a 36-dword tail
+    // (hi: dwords {1.0, 0}, the operand of the bias k-slot; lo: zeros) that lane group 3 reads at a
+    // bank offset 16 away from lane group 2's dwords
+    static constexpr int PATCH_TAIL = 144;
+    static constexpr int PATCH_BYTES = MODE == SRC_STEM ? 2 * (PATCH_H * PATCH_W * 4 + PATCH_TAIL) : 0;
     // CONCAT_UP: the bilinear mapping of this tile, one 16-B entry per in-tile row and per in-tile
     // pixel column (same for every plane, so it is evaluated once per tile, not per plane)
     static constexpr int TAB_OFF = PATCH_OFF + ((PATCH_BYTES + 255) / 256) * 256;
@@ -1005,7 +1038,7 @@ __global__ __launch_bounds__(256, conv_occupancy(BN, TH, TW)) void conv3x3_mfma_
         if constexpr (MODE == SRC_STEM) {
             unsigned short* const ph = reinterpret_cast<unsigned short*>(patch);
             unsigned short* const pl = reinterpret_cast<unsigned short*>(patch + PATCH_HALF);
-            constexpr int NE = PATCH_HALF / 2;        // elements incl. the zero pad at the end
+            constexpr int NE = PATCH_HALF / 2;        // elements incl. the tail
             constexpr int NB = (NE + 255) / 256;      // all loads are issued before the first use
             float v[NB];
 #pragma unroll
@@ -1017,12 +1050,15 @@ __global__ __launch_bounds__(256, conv_occupancy(BN, TH, TW)) void conv3x3_mfma_
                 const bool ok = (i < NE) & (py < PH) & (y >= 0) & (y < aH) & (x >= 0) & (x < aW);
                 const float* src = f ? a.f2 : a.f1;
                 v[k] = ok ? src[((size_t)b * aH + (ok ? y : 0)) * aW + (ok ? x : 0)] : 0.f;
+                // ordered input dither, +d on frame 1 and -d on frame 2 (stem_dither); the conv's zero
+                // padding stays exactly zero
+                if (ok) v[k] = v[k] + (f ? -a.dither : a.dither) * stem_dither(y, x);
             }
 #pragma unroll
             for (int k = 0; k < NB; ++k) {
                 const int i = tid + k * 256;
-                // the 64-B pad behind the hi image holds 1.0s (lo: zeros): the operand of the bias slot
-                const unsigned hi = i < PH * PW * 2 ? pack_bf16x2(v[k], 0.f) & 0xffffu : 0x3f80u;
+                // tail behind the hi image: dwords {1.0, 0} (lo: zeros): the operand of the bias k-slot
+                const unsigned hi = i < PH * PW * 2 ? pack_bf16x2(v[k], 0.f) & 0xffffu : ((i & 1) ? 0u : 0x3f80u);
                 const unsigned lo = pack_bf16x2(v[k] - __uint_as_float(hi << 16), 0.f) & 0xffffu;
                 if (i < NE) { ph[i] = (unsigned short)hi; pl[i] = (unsigned short)(i < PH * PW * 2 ? lo : 0u); }
             }
@@ -1060,20 +1096,22 @@ __global__ __launch_bounds__(256, conv_occupancy(BN, TH, TW)) void conv3x3_mfma_
     };
     auto gather_plane_stem = [&](const StemW& w) __attribute__((always_inline)) {
         if constexpr (MODE == SRC_STEM) {
-            // lane group 3 (k = 24..31) reads the row of 1.0s behind the hi image / zeros behind lo
-            const int drow = lc < 3 ? lc * PW : PH * PW;
+            // lane groups 0, 1, 2 read patch rows py, py+2, py+1 (so that the two groups served together
+            // by a ds_read2_b32, lanes 0-31, sit 2 * PW = 16 banks apart); lane group 3 (k = 24..31, only
+            // k = 24 has a weight: the BatchNorm shift) reads {1.0, 0} dwords from the tail behind the hi
+            // image / zeros behind lo, at the bank offset 16 away from lane group 2's dwords
+            const int drow = lc == 0 ? 0 : (lc == 1 ? 2 * PW : PW);
             const unsigned* const ph32 = reinterpret_cast<const unsigned*>(patch);
             const unsigned* const pl32 = reinterpret_cast<const unsigned*>(patch + PATCH_HALF);
-            // this lane's 8 bytes of a 64-B record for cout tile h = 0 (h = 1: the chunk two further,
-            // i.e. address ^ 32 after the row swizzle, which flips the same bit)
-            const int lane_wr = (lc >> 1) * 16 + (lc & 1) * 8;
+            static_assert((PH * PW) % 32 == 0 && Tile::PATCH_TAIL >= (32 + 4) * 4, "tail bank arithmetic");
             struct Frag { uint4 bh, bl; int dst; };  // dst < 0: lane beyond the in-tile; bit 30: outside the image
             // A wave's fragments are 64 in-tile pixels apart: (py, px) advance by constants with one
             // conditional wrap.  Lanes past the last pixel read a clamped row and store nothing.
             constexpr int DY = 64 / (TW + 2), DX = 64 % (TW + 2);
             int py = (wave * 16 + l15) / (TW + 2), px = wave * 16 + l15 - py * (TW + 2);
             auto fetch = [&](Frag& f) __attribute__((always_inline)) {
-                const int e = lc < 3 ? (int)__umul24(min(py, THP - 1), PW) + px + drow : drow;  // v_mad_u32_u24, not the 64-bit mad
+                const int em = (int)__umul24(min(py, THP - 1), PW) + px + drow;  // v_mad_u32_u24, not the 64-bit mad
+                const int e = lc < 3 ? em : PH * PW + ((em + 16) & 31);
                 f.bh = make_uint4(ph32[e], ph32[e + 1], ph32[e + 2], ph32[e + 3]);
                 f.bl = make_uint4(pl32[e], pl32[e + 1], pl32[e + 2], pl32[e + 3]);
                 const bool ok = ((unsigned)(y0 - 1 + py) < (unsigned)aH) & ((unsigned)(x0 - 1 + px) < (unsigned)aW);
@@ -1091,16 +1129,17 @@ __global__ __launch_bounds__(256, conv_occupancy(BN, TH, TW)) void conv3x3_mfma_
                 for (int h = 0; h < 2; ++h) mma_chunk<T>(s4[h], w.wh[h], f.bl);
 #pragma unroll
                 for (int h = 0; h < 2; ++h) mma_chunk<T>(s4[h], w.wh[h], f.bh);
+                // packed row lc*4 + j of tile h is channel lc*8 + h*4 + j of the plane (host:
+                // bf16_row_to_cout): the lane's 8 values are ONE 16-B chunk of the pixel's record - one
+                // ds_write_b128 (2-way bank conflicts) instead of two ds_write_b64 (4-way)
                 const int row = f.dst & 0xffff;
                 const bool zero = (f.dst >> 30) & 1;
-                const int a0 = row * 64 + (lane_wr ^ (((row >> 2) & 1) << 5));
-#pragma unroll
-                for (int h = 0; h < 2; ++h) {
-                    const unsigned p0 = relu_pk_bf16(pack_bf16x2_pk(s4[h][0], s4[h][1]));
-                    const unsigned p1 = relu_pk_bf16(pack_bf16x2_pk(s4[h][2], s4[h][3]));
-                    const uint2 pk = zero ? make_uint2(0u, 0u) : make_uint2(p0, p1);
-                    if (f.dst >= 0) *reinterpret_cast<uint2*>(lds_in + (a0 ^ (h * 32))) = pk;
-                }
+                uint4 pk = make_uint4(relu_pk_bf16(pack_bf16x2_pk(s4[0][0], s4[0][1])),
+                                      relu_pk_bf16(pack_bf16x2_pk(s4[0][2], s4[0][3])),
+                                      relu_pk_bf16(pack_bf16x2_pk(s4[1][0], s4[1][1])),
+                                      relu_pk_bf16(pack_bf16x2_pk(s4[1][2], s4[1][3])));
+                if (zero) pk = make_uint4(0u, 0u, 0u, 0u);
+                if (f.dst >= 0) *reinterpret_cast<uint4*>(lds_in + row * 64 + ((lc ^ swz(row)) << 4)) = pk;
             };
             // two fragments per trip, operands of the next one in flight during the MFMAs of this one
             constexpr int NQ = (NIN + 15) / 16;

@@ -465,6 +465,9 @@ int forward_impl(fiunet_ctx* ctx, const float* f1, const float* f2, float* out, 
     const bool fuse_stem = po.fused_stem || (bf16 && ctx->cf == 1 && !unfused && ctx->stem_w_split != nullptr &&
                                              prefer_wide(H, W, 16, 32, 32, 16));
     const bool run_stem = !po.fused_stem;
+    // bf16 only: ordered input dither of the stem (conv3x3_mfma.hip.h, stem_dither); 2^-8 = a quarter of
+    // an 8-bit input step peak to peak
+    const float stem_dither_amp = (bf16 && !(ctx->flags & FIUNET_OPT_NO_DITHER)) ? 0.00390625f : 0.f;
     // conv 0: fp32 stem (unet.py:72, first conv of inc)
     if (run_stem) {
         const ConvWeights& cw = ctx->conv[0];
@@ -472,10 +475,10 @@ int forward_impl(fiunet_ctx* ctx, const float* f1, const float* f2, float* out, 
         dim3 grid((unsigned)std::min<long long>((nruns + 3) / 4, 256 * 64));
         if (ctx->cf == 1)
             hipLaunchKernelGGL((conv3x3_first_kernel<T, 1>), grid, dim3(256), 0, s, f1, f2,
-                               (const float*)cw.w_f32, cw.scale, cw.shift, act(0), B, H, W);
+                               (const float*)cw.w_f32, cw.scale, cw.shift, act(0), B, H, W, stem_dither_amp);
         else
             hipLaunchKernelGGL((conv3x3_first_kernel<T, 3>), grid, dim3(256), 0, s, f1, f2,
-                               (const float*)cw.w_f32, cw.scale, cw.shift, act(0), B, H, W);
+                               (const float*)cw.w_f32, cw.scale, cw.shift, act(0), B, H, W, stem_dither_amp);
         HIP_TRY(hipGetLastError());
     }
     if (ev) {
@@ -539,6 +542,7 @@ int forward_impl(fiunet_ctx* ctx, const float* f1, const float* f2, float* out, 
             mode = SRC_STEM;
             a.f1 = f1; a.f2 = f2;
             a.stem_w = ctx->stem_w_split;
+            a.dither = stem_dither_amp;
         }
         if (unfused && mode == SRC_CONCAT_UP) {
             const size_t n = (size_t)B * a.H * a.W * ((a.C0 + a.C1) * sizeof(T) / 16);
@@ -653,6 +657,7 @@ int fiunet_load_weights(fiunet_ctx* ctx, int n, const char* const* names,
     };
     free_weights(ctx);
     const int cin0 = 2 * ctx->cf;
+    const bool rne_weights = ctx->flags & FIUNET_OPT_RNE_WEIGHTS;  // read at LOAD time
     for (int i = 0; i < NCONV; ++i) {
         const int blk = i / 2, second = i % 2;
         const std::string pre = std::string(kBlockPrefix[blk]) + ".double_conv.";
@@ -688,27 +693,28 @@ int fiunet_load_weights(fiunet_ctx* ctx, int n, const char* const* names,
                     for (int t = 0; t < 9; ++t)
                         pk[((size_t)t * cin + ci) * 64 + co] = w[((size_t)co * cin + ci) * 9 + t];
             if ((rc = dev_upload(ctx, pk.data(), pk.size() * 4, &cw.w_f32))) return rc;
-            if (cin == 2) {  // fused-stem copy: w = hi + lo in bf16, [hi|lo][cout][k = dy*8 + dx*2 + frame]
+            if (cin == 2) {  // fused-stem copy: w = hi + lo in bf16, [hi|lo][packed row][k]
+                // packed row P = plane*32 + tile*16 + r holds cout bf16_row_to_cout(P), so that a lane of the
+                // stem MFMAs ends up with 8 consecutive channels (one 16-B chunk of the in-tile record);
+                // k = lane group*8 + dx*2 + frame with lane groups 0, 1, 2 <-> dy = 0, 2, 1 (LDS banks of the
+                // patch reads, conv3x3_mfma.hip.h) and k = 24 = the BatchNorm shift (operand 1.0)
                 std::vector<uint16_t> sp((size_t)2 * 64 * 32, 0);
-                for (int co = 0; co < 64; ++co)
-                    for (int k = 0; k < 24; ++k) {
-                        const int dy = k >> 3, dx = (k >> 1) & 3, f = k & 1;
-                        if (dx == 3) continue;
-                        const float v = w[((size_t)co * 2 + f) * 9 + dy * 3 + dx] * sc[co];  // BatchNorm scale folded in
+                static const int kLaneGroupOfDy[3] = {0, 2, 1};
+                for (int P = 0; P < 64; ++P) {
+                    const int co = bf16_row_to_cout(P);
+                    auto put = [&](int k, float v) {
                         const uint16_t hi = f32_to_bf16_rne(v);
                         uint32_t hb = (uint32_t)hi << 16;
                         float hf;
                         std::memcpy(&hf, &hb, 4);
-                        sp[(size_t)co * 32 + k] = hi;
-                        sp[(size_t)64 * 32 + co * 32 + k] = f32_to_bf16_rne(v - hf);
-                    }
-                for (int co = 0; co < 64; ++co) {  // k = 24: BatchNorm shift (the kernel feeds 1.0 there)
-                    const uint16_t hi = f32_to_bf16_rne(sh[co]);
-                    uint32_t hb = (uint32_t)hi << 16;
-                    float hf;
-                    std::memcpy(&hf, &hb, 4);
-                    sp[(size_t)co * 32 + 24] = hi;
-                    sp[(size_t)64 * 32 + co * 32 + 24] = f32_to_bf16_rne(sh[co] - hf);
+                        sp[(size_t)P * 32 + k] = hi;
+                        sp[(size_t)64 * 32 + P * 32 + k] = f32_to_bf16_rne(v - hf);
+                    };
+                    for (int dy = 0; dy < 3; ++dy)
+                        for (int dx = 0; dx < 3; ++dx)
+                            for (int f = 0; f < 2; ++f)  // BatchNorm scale folded in
+                                put(kLaneGroupOfDy[dy] * 8 + dx * 2 + f, w[((size_t)co * 2 + f) * 9 + dy * 3 + dx] * sc[co]);
+                    put(24, sh[co]);
                 }
                 if ((rc = dev_upload(ctx, sp.data(), sp.size() * 2, &ctx->stem_w_split))) return rc;
             }
@@ -729,8 +735,9 @@ int fiunet_load_weights(fiunet_ctx* ctx, int n, const char* const* names,
                     // rounding for the bf16 copy), its shift into the accumulators' initial value
                     p32[(((size_t)(ci / 16) * 9 + slot) * cout + R) * 16 + (ci % 16)] =
                         w[((size_t)R * cin + ci) * 9 + t] * sc[R];
+                    const float wv = w[((size_t)co16 * cin + ci) * 9 + t] * sc[co16];
                     p16[(((size_t)(ci / 32) * 9 + slot) * cout + R) * 32 + (ci % 32)] =
-                        f32_to_bf16_feedback(w[((size_t)co16 * cin + ci) * 9 + t] * sc[co16], carry);
+                        rne_weights ? f32_to_bf16_rne(wv) : f32_to_bf16_feedback(wv, carry);
                 }
         }
         if ((rc = dev_upload(ctx, p32.data(), nel * 4, &cw.w_f32))) return rc;
@@ -895,6 +902,65 @@ int fiunet_ssim_u8(const uint8_t* pred, const uint8_t* target, int images, int H
     HIP_TRY(hipGetLastError());
     const double count = (double)(H - 2 * SSIM_PAD) * (double)(W - 2 * SSIM_PAD);
     hipLaunchKernelGGL(ssim_finalize_kernel, dim3((unsigned)images), dim3(256), 0, s, partial, tiles, count, out);
+    HIP_TRY(hipGetLastError());
+    return FIUNET_OK;
+}
+
+static inline int gssim_tiles(int H, int W, int* tiles_x)
+{
+    const int tx = (W + GSSIM_TX - 1) / GSSIM_TX, ty = (H + GSSIM_TY - 1) / GSSIM_TY;
+    if (tiles_x) *tiles_x = tx;
+    return tx * ty;
+}
+
+size_t fiunet_ssim_gauss_workspace_bytes(int images, int H, int W)
+{
+    if (images < 1 || H < 1 || W < 1) {
+        g_err = "fiunet_ssim_gauss_workspace_bytes: bad arguments";
+        return 0;
+    }
+    return align256((size_t)images * gssim_tiles(H, W, nullptr) * 2 * 8);
+}
+
+int fiunet_ssim_gauss_f32(const float* img1, const float* img2, int images, int H, int W, int window_size,
+                          double* out_ssim, double* out_sqerr, void* workspace, size_t workspace_bytes,
+                          void* stream)
+{
+    if (!img1 || !img2 || !out_ssim || !workspace) return fail(FIUNET_ERR_INVALID_ARG, "NULL argument");
+    if (images < 1 || H < 1 || W < 1) return fail(FIUNET_ERR_BAD_SHAPE, "bad image shape");
+    if (images > 65535) return fail(FIUNET_ERR_INVALID_ARG, "more than 65535 planes per call");
+    if (window_size < 1 || window_size > 2 * GSSIM_MAXR + 1 || !(window_size & 1))
+        return fail(FIUNET_ERR_UNSUPPORTED, "Gaussian SSIM: window_size must be odd and <= 31 (an even window "
+                                            "changes the map size in the reference: padding = window_size//2)");
+    if (workspace_bytes < fiunet_ssim_gauss_workspace_bytes(images, H, W))
+        return fail(FIUNET_ERR_WORKSPACE, "workspace too small");
+    if ((uintptr_t)workspace & 255) return fail(FIUNET_ERR_INVALID_ARG, "workspace not 256-B aligned");
+    // train.py:27-29: fp32 tensor of exp(-(x - ws//2)^2 / (2 sigma^2)) (evaluated in double by numpy), sigma =
+    // 1.5 (:32), divided by its fp32 sum
+    const int R = window_size / 2;
+    GaussWindow win;
+    float sum = 0.f;
+    for (int x = 0; x < window_size; ++x) {
+        win.g[x] = (float)std::exp(-(double)((x - R) * (x - R)) / (2.0 * 1.5 * 1.5));
+        sum += win.g[x];
+    }
+    for (int x = 0; x < window_size; ++x) win.g[x] /= sum;
+    for (int x = window_size; x < 2 * GSSIM_MAXR + 1; ++x) win.g[x] = 0.f;
+    hipStream_t s = (hipStream_t)stream;
+    int tx = 0;
+    const int tiles = gssim_tiles(H, W, &tx);
+    double* partial = (double*)workspace;
+    const int IH = GSSIM_TY + 2 * R, IW = GSSIM_TX + 2 * R;
+    const size_t lds = (size_t)5 * IH * GSSIM_TX * 8 + (size_t)2 * IH * (IW + 1) * 4;
+    if (R == 5)
+        hipLaunchKernelGGL((ssim_gauss_f32_kernel<5>), dim3((unsigned)tiles, (unsigned)images), dim3(256), lds, s,
+                           img1, img2, H, W, tx, R, win, partial);
+    else
+        hipLaunchKernelGGL((ssim_gauss_f32_kernel<0>), dim3((unsigned)tiles, (unsigned)images), dim3(256), lds, s,
+                           img1, img2, H, W, tx, R, win, partial);
+    HIP_TRY(hipGetLastError());
+    hipLaunchKernelGGL(ssim_gauss_finalize_kernel, dim3((unsigned)images), dim3(256), 0, s, partial, tiles,
+                       (double)H * (double)W, out_ssim, out_sqerr);
     HIP_TRY(hipGetLastError());
     return FIUNET_OK;
 }

@@ -157,4 +157,139 @@ __global__ __launch_bounds__(256) void ssim_finalize_kernel(const double* __rest
     if (tid == 0) out[blockIdx.x] = red[0] / count;
 }
 
+
+// ---------------------------------------------------------------------------------------------------
+// Gaussian-window SSIM of the training loss (/root/reference/model/train.py:18-73, SSIMLoss._ssim):
+// depth-wise conv2d of img1, img2, img1*img1, img2*img2, img1*img2 with the normalised
+// window_size x window_size Gaussian (sigma 1.5, :27-35), ZERO padding window_size//2 (:38-46),
+// C1 = 0.01^2, C2 = 0.03^2 (:48-49), map = (2 mu1 mu2 + C1)(2 s12 + C2) / ((mu1^2 + mu2^2 + C1)(s1 + s2 + C2))
+// (:51), then a mean (:53-56).  fp32 planes in the caller's value range (the loss is applied to [0,1]
+// tensors, train.py:142,192).  The reference's window is the outer product of the normalised 1-D
+// Gaussian, so the filter is evaluated separably: horizontal 11-tap sums into LDS, vertical 11-tap sums
+// in registers.  The three products are rounded to fp32 first, as the reference's `img1*img1` tensors
+// are; all sums, the map and its mean are fp64 in a fixed order (deterministic; the reference's own fp32
+// conv carries ~1e-7 of rounding that this does not reproduce, far below the 1e-5 the tests ask for).
+// The same pass also returns sum (img1 - img2)^2 per plane for CombinedLoss' MSE term (train.py:75-87).
+// Roofline: HBM (8 bytes read per pixel).
+constexpr int GSSIM_TX = 64, GSSIM_TY = 16, GSSIM_MAXR = 15;
+struct GaussWindow { float g[2 * GSSIM_MAXR + 1]; };  // by value in the kernel arguments
+
+// grid = (tiles_x * tiles_y, planes); dynamic LDS: 2 fp32 input tiles + 5 fp64 row-sum planes.
+// RT > 0: window radius known at compile time (the reference only ever uses 5); RT == 0: runtime r.
+template <int RT>
+__global__ __launch_bounds__(256) void ssim_gauss_f32_kernel(const float* __restrict__ a,
+                                                             const float* __restrict__ b, int H, int W,
+                                                             int tiles_x, int r_arg, GaussWindow win,
+                                                             double* __restrict__ partial)
+{
+    const int R = RT > 0 ? RT : r_arg;
+    const int IW = GSSIM_TX + 2 * R, IH = GSSIM_TY + 2 * R, IWP = IW + 1;
+    extern __shared__ double gssim_lds[];
+    double* hs = gssim_lds;                                    // [5][IH][TX]
+    float* ta = reinterpret_cast<float*>(hs + 5 * IH * GSSIM_TX);  // [IH][IWP]
+    float* tb = ta + IH * IWP;
+    __shared__ double red[2][256];
+    const int tid = threadIdx.x;
+    const int tile = blockIdx.x, tx = tile % tiles_x, ty = tile / tiles_x;
+    const size_t img = blockIdx.y;
+    const float* pa = a + img * (size_t)H * W;
+    const float* pb = b + img * (size_t)H * W;
+    const int oy0 = ty * GSSIM_TY, ox0 = tx * GSSIM_TX;
+    double sq = 0.0;
+    for (int i = tid; i < IH * IW; i += 256) {
+        const int rr = i / IW, c = i - rr * IW;
+        const int y = oy0 + rr - R, x = ox0 + c - R;
+        const bool in = y >= 0 && y < H && x >= 0 && x < W;  // F.conv2d padding: zeros
+        const float va = in ? pa[(size_t)y * W + x] : 0.f, vb = in ? pb[(size_t)y * W + x] : 0.f;
+        ta[rr * IWP + c] = va;
+        tb[rr * IWP + c] = vb;
+        // every image pixel belongs to exactly one tile's interior
+        if (in && rr >= R && rr < R + GSSIM_TY && c >= R && c < R + GSSIM_TX) {
+            const float d = va - vb;  // nn.MSELoss: fp32 difference
+            sq += (double)d * (double)d;
+        }
+    }
+    __syncthreads();
+    for (int i = tid; i < IH * GSSIM_TX; i += 256) {
+        const int rr = i / GSSIM_TX, c = i - rr * GSSIM_TX;
+        double s0 = 0, s1 = 0, s2 = 0, s3 = 0, s4 = 0;
+#pragma unroll
+        for (int k = 0; k < 2 * R + 1; ++k) {
+            const float va = ta[rr * IWP + c + k], vb = tb[rr * IWP + c + k];
+            const double g = (double)win.g[k];
+            s0 = fma(g, (double)va, s0);
+            s1 = fma(g, (double)vb, s1);
+            s2 = fma(g, (double)(va * va), s2);
+            s3 = fma(g, (double)(vb * vb), s3);
+            s4 = fma(g, (double)(va * vb), s4);
+        }
+        hs[(0 * IH + rr) * GSSIM_TX + c] = s0;
+        hs[(1 * IH + rr) * GSSIM_TX + c] = s1;
+        hs[(2 * IH + rr) * GSSIM_TX + c] = s2;
+        hs[(3 * IH + rr) * GSSIM_TX + c] = s3;
+        hs[(4 * IH + rr) * GSSIM_TX + c] = s4;
+    }
+    __syncthreads();
+    const double C1 = 0.01 * 0.01, C2 = 0.03 * 0.03;
+    double acc = 0.0;
+    for (int i = tid; i < GSSIM_TY * GSSIM_TX; i += 256) {
+        const int rr = i / GSSIM_TX, c = i - rr * GSSIM_TX;
+        if (oy0 + rr >= H || ox0 + c >= W) continue;
+        double s[5] = {0, 0, 0, 0, 0};
+#pragma unroll
+        for (int k = 0; k < 2 * R + 1; ++k) {
+            const double g = (double)win.g[k];
+#pragma unroll
+            for (int q = 0; q < 5; ++q) s[q] = fma(g, hs[(q * IH + rr + k) * GSSIM_TX + c], s[q]);
+        }
+        const double mu1 = s[0], mu2 = s[1];
+        const double mu1_sq = mu1 * mu1, mu2_sq = mu2 * mu2, mu1_mu2 = mu1 * mu2;
+        const double s1 = s[2] - mu1_sq, s2 = s[3] - mu2_sq, s12 = s[4] - mu1_mu2;
+        acc += ((2.0 * mu1_mu2 + C1) * (2.0 * s12 + C2)) / ((mu1_sq + mu2_sq + C1) * (s1 + s2 + C2));
+    }
+    red[0][tid] = acc;
+    red[1][tid] = sq;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if (tid < o) {
+            red[0][tid] += red[0][tid + o];
+            red[1][tid] += red[1][tid + o];
+        }
+        __syncthreads();
+    }
+    if (tid == 0) {
+        partial[(img * gridDim.x + tile) * 2 + 0] = red[0][0];
+        partial[(img * gridDim.x + tile) * 2 + 1] = red[1][0];
+    }
+}
+
+// one workgroup per plane: fixed-order sums of the tile partials -> mean SSIM map, sum of squared error
+__global__ __launch_bounds__(256) void ssim_gauss_finalize_kernel(const double* __restrict__ partial, int tiles,
+                                                                  double count, double* __restrict__ out_ssim,
+                                                                  double* __restrict__ out_sqerr)
+{
+    __shared__ double red[2][256];
+    const int tid = threadIdx.x;
+    const double* p = partial + (size_t)blockIdx.x * tiles * 2;
+    double acc = 0.0, sq = 0.0;
+    for (int i = tid; i < tiles; i += 256) {
+        acc += p[2 * i];
+        sq += p[2 * i + 1];
+    }
+    red[0][tid] = acc;
+    red[1][tid] = sq;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if (tid < o) {
+            red[0][tid] += red[0][tid + o];
+            red[1][tid] += red[1][tid + o];
+        }
+        __syncthreads();
+    }
+    if (tid == 0) {
+        out_ssim[blockIdx.x] = red[0][0] / count;
+        if (out_sqerr) out_sqerr[blockIdx.x] = red[1][0];
+    }
+}
+
 }  // namespace fiunet

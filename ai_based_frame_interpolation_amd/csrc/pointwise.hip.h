@@ -27,8 +27,10 @@ template <typename T, int CF>
 __global__ __launch_bounds__(256) void conv3x3_first_kernel(
     const float* __restrict__ f1, const float* __restrict__ f2, const float* __restrict__ w,
     const float* __restrict__ scale, const float* __restrict__ shift, T* __restrict__ dst, int B,
-    int H, int W)
+    int H, int W, float dither)
 {
+    // dither: amplitude of the ordered input dither of the bf16 path (stem_dither in
+    // conv3x3_mfma.hip.h: +d on frame 1, -d on frame 2, same values as the fused stem); 0 = off (fp32)
     constexpr int K = 9 * 2 * CF, KG = (K + 3) / 4;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int l15 = lane & 15, lc = lane >> 4;
@@ -81,6 +83,11 @@ __global__ __launch_bounds__(256) void conv3x3_first_kernel(
             for (int g = 0; g < KG; ++g) {
                 const int xx = x + dxs[g];
                 v[g] = (xx >= 0 && xx < W) ? p[g][(xt - xt0) * 16 + dxs[g]] : 0.f;
+                if constexpr (sizeof(T) == 2) {  // the conv's zero padding stays exactly zero
+                    // (row and frame of this k-slot are re-derived from koff: no registers held for them)
+                    if (xx >= 0 && xx < W)
+                        v[g] = v[g] + ((koff[g] >> 4) >= CF ? -dither : dither) * stem_dither(y + (koff[g] & 3) - 1, xx);
+                }
             }
         };
         float vn[KG];

@@ -192,10 +192,23 @@ class FrameInterpolationUNet(nn.Module):
         self._ctx_dirty = True
 
     def set_options(self, *, unfused: bool = False, keep_all: bool = False, pair_tiles: bool = False,
-                    gather_upsample: bool = False):
+                    gather_upsample: bool = False, rne_weights: bool = False, no_dither: bool = False):
+        """unfused / keep_all / pair_tiles / gather_upsample: ablation and test switches (include/fiunet.h).
+        rne_weights: bf16 weights rounded to nearest instead of with the per-filter error feedback;
+        no_dither: no ordered input dither in the bf16 stem - both for comparing a real checkpoint both
+        ways (the defaults are what the PSNR criterion was measured with)."""
+        old = self._options
         self._options = ((_native.OPT_UNFUSED if unfused else 0) | (_native.OPT_KEEP_ALL if keep_all else 0)
                          | (_native.OPT_PAIR_TILES if pair_tiles else 0)
-                         | (_native.OPT_GATHER_UPSAMPLE if gather_upsample else 0))
+                         | (_native.OPT_GATHER_UPSAMPLE if gather_upsample else 0)
+                         | (_native.OPT_RNE_WEIGHTS if rne_weights else 0)
+                         | (_native.OPT_NO_DITHER if no_dither else 0))
+        if (old ^ self._options) & _native.OPT_RNE_WEIGHTS:
+            self._ctx_dirty = True  # the rounding mode is applied when the weights are prepared
+        if self._ctx is not None:
+            self._ctx.set_options(self._options)
+
+    def _ctx_or_none_set_options(self):
         if self._ctx is not None:
             self._ctx.set_options(self._options)
 
@@ -208,8 +221,8 @@ class FrameInterpolationUNet(nn.Module):
             self._ctx_dirty = True
         fp = self._current_fingerprint()
         if self._ctx_dirty or fp != self._fingerprint:
+            self._ctx.set_options(self._options)  # (the weight-rounding option is read at load time)
             self._ctx.load_state_dict(self.state_dict())
-            self._ctx.set_options(self._options)
             self._ctx_dirty = False
             self._fingerprint = fp
             self._weights_gen += 1
@@ -296,9 +309,8 @@ class FrameInterpolationUNet(nn.Module):
         """Parity-test hook: run one forward keeping every stage and return
         ({tap name: fp32 NCHW tensor}, output)."""
         saved = self._options
-        self.set_options(unfused=bool(saved & _native.OPT_UNFUSED), keep_all=True,
-                         pair_tiles=bool(saved & _native.OPT_PAIR_TILES),
-                         gather_upsample=bool(saved & _native.OPT_GATHER_UPSAMPLE))
+        self._options = saved | _native.OPT_KEEP_ALL
+        self._ctx_or_none_set_options()
         try:
             out = self.forward(frame1, frame2)
             b, _, h, w = frame1.shape

@@ -141,7 +141,8 @@ class _Null:
 def interpolate_video_sharded(pair_fn: Callable[[torch.Tensor, torch.Tensor], torch.Tensor],
                               frames: Optional[torch.Tensor], n_frames: int, frame_shape, device,
                               batch: int = 8, root: int = 0, group=None,
-                              out: Optional[torch.Tensor] = None) -> Optional[torch.Tensor]:
+                              out: Optional[torch.Tensor] = None,
+                              trace: Optional[list] = None) -> Optional[torch.Tensor]:
     """factor-2 interpolation of a video held by `root` (uint8 `[n_frames, *frame_shape]` on
     `device`): every rank forwards its own contiguous pair range with
     `pair_fn(F[i:i+b], F[i+1:i+b+1]) -> M` (uint8 in, uint8 out; on the GPU this is
@@ -149,7 +150,23 @@ def interpolate_video_sharded(pair_fn: Callable[[torch.Tensor, torch.Tensor], to
     and the gather of sub-batch j-1 in flight while sub-batch j is being forwarded.
     Returns the interleaved `[2n-1, ...]` stack on `root` (written into `out` if given), None
     elsewhere.  Every rank issues its sends/recvs towards a given peer in the same order
-    (scatter 0, scatter 1, gather 0, scatter 2, gather 1, ...), so the pipeline cannot deadlock."""
+    (scatter 0, scatter 1, gather 0, scatter 2, gather 1, ...), so the pipeline cannot deadlock;
+    `trace`, if given, receives one `(op, peer, kind, j, frames)` tuple per issued transfer in issue
+    order (tests/test_dist.py compares the two ends of every link).
+
+    Buffers and streams (all of it a no-op on CPU tensors).  Two streams touch every transfer buffer:
+    the comm stream (where the send/recv is issued and, on root, where received middles are
+    interleaved into `out`) and the compute stream (where `pair_fn` reads the frames and writes the
+    middles).  Nothing here relies on the caching allocator for ordering:
+      * a non-root rank receives into a RING of three pre-allocated `[batch+1, ...]` buffers (the recv
+        of sub-batch j+1 is issued while sub-batch j-1 may still be running, so three are live at
+        most); before a slot is received into, the comm stream waits for the compute stream, i.e. for
+        the forward that last read that slot;
+      * root receives middles into per-peer staging buffers from a ring of two sets, allocated up
+        front; they are only ever touched from the comm stream, in its order;
+      * a rank's middles are allocated by `pair_fn` on the compute stream; the comm stream waits for
+        the compute stream before the send and the tensor is `record_stream`-ed on the comm stream
+        before its reference is dropped."""
     rank, world = dist.get_rank(group), dist.get_world_size(group)
     shape = tuple(frame_shape)
     parts = partition_pairs(n_frames, world)
@@ -163,9 +180,23 @@ def interpolate_video_sharded(pair_fn: Callable[[torch.Tensor, torch.Tensor], to
         out[0::2] = frames
     my_first, my_cnt = parts[rank]
     my_subs = subs[rank]
-    recv_buf = {}   # non-root: sub-batch j's frames
-    mids = {}       # sub-batch j's middles (kept until their send / copy has been issued)
-    pending = []    # gather works not yet known to be complete
+    mids = {}       # sub-batch j's middles (kept until their send has been issued)
+    pending = []    # works not yet known to be complete
+    RING = 3
+    recv_ring = stage_ring = None
+    # pre-allocated transfer buffers.  They come from the compute stream's pool, so a kernel queued there
+    # earlier may still be using the same bytes: every transfer INTO them is issued after a
+    # comm_after_compute() (scatter_step / gather_step), which orders it behind all of that
+    if not is_root and my_subs:
+        recv_ring = [torch.empty((batch + 1,) + shape, dtype=torch.uint8, device=device)
+                     for _ in range(min(RING, len(my_subs)))]
+    if is_root and world > 1:
+        stage_ring = [{r: torch.empty((batch,) + shape, dtype=torch.uint8, device=device)
+                       for r in range(world) if r != root and subs[r]} for _ in range(2)]
+
+    def note(op, peer, kind, j, n):
+        if trace is not None:
+            trace.append((op, peer, kind, j, n))
 
     def scatter_step(j):
         """root -> every peer that has a j-th sub-batch (one grouped launch: 7 links in parallel)."""
@@ -176,17 +207,21 @@ def interpolate_video_sharded(pair_fn: Callable[[torch.Tensor, torch.Tensor], to
                     o, c = subs[r][j]
                     a = parts[r][0] + o
                     ops.append(dist.P2POp(dist.isend, frames[a:a + c + 1], r, group))
+                    note("send", r, "scatter", j, c + 1)
         elif j < len(my_subs):
             o, c = my_subs[j]
-            recv_buf[j] = torch.empty((c + 1,) + shape, dtype=torch.uint8, device=device)
-            ops.append(dist.P2POp(dist.irecv, recv_buf[j], root, group))
+            # slot j % RING was last read by the forward of sub-batch j - RING, queued on the compute
+            # stream at least two loop iterations ago: order the receive after it
+            st.comm_after_compute()
+            ops.append(dist.P2POp(dist.irecv, recv_ring[j % RING][:c + 1], root, group))
+            note("recv", root, "scatter", j, c + 1)
         if not ops:
             return []
         with st.on_comm():
             return dist.batch_isend_irecv(ops)
 
     def gather_step(j):
-        """every peer's j-th middles -> root, straight into the interleaved output."""
+        """every peer's j-th middles -> root, then (comm stream) into the interleaved output."""
         ops = []
         if is_root:
             for r in range(world):
@@ -194,11 +229,14 @@ def interpolate_video_sharded(pair_fn: Callable[[torch.Tensor, torch.Tensor], to
                     o, c = subs[r][j]
                     a = parts[r][0] + o
                     # odd rows of `out` are strided views; receive into a contiguous staging
-                    # tensor and let the comm stream interleave it afterwards
-                    stage = torch.empty((c,) + shape, dtype=torch.uint8, device=device)
+                    # tensor and let the comm stream interleave it afterwards.  Set j % 2 was last
+                    # used by gather j - 2, whose interleave copy is earlier on this same stream.
+                    stage = stage_ring[j % 2][r][:c]
                     ops.append((dist.P2POp(dist.irecv, stage, r, group), (a, c, stage)))
+                    note("recv", r, "gather", j, c)
         elif j < len(my_subs):
             ops.append((dist.P2POp(dist.isend, mids[j], root, group), None))
+            note("send", root, "gather", j, int(mids[j].shape[0]))
         if not ops:
             return []
         st.comm_after_compute()  # the middles of step j are queued on the compute stream
@@ -209,9 +247,9 @@ def interpolate_video_sharded(pair_fn: Callable[[torch.Tensor, torch.Tensor], to
                     w.wait()  # comm stream waits for the receives, then interleaves
                 for _, (a, c, stage) in ops:
                     out[2 * a + 1:2 * (a + c):2] = stage
-                    if st.cuda:
-                        stage.record_stream(st.comm)
                 return []  # already waited for (a second wait() on a gloo work never returns)
+            if st.cuda:
+                mids[j].record_stream(st.comm)  # allocated on the compute stream, read by the send
         return works
 
     inflight = {0: scatter_step(0)} if nsteps else {}
@@ -228,7 +266,7 @@ def interpolate_video_sharded(pair_fn: Callable[[torch.Tensor, torch.Tensor], to
             if is_root:
                 src = frames[my_first + o:my_first + o + c + 1]
             else:
-                src = recv_buf.pop(j)
+                src = recv_ring[j % RING][:c + 1]
             m = pair_fn(src[:c], src[1:c + 1])
             if is_root:
                 a = my_first + o
@@ -236,6 +274,12 @@ def interpolate_video_sharded(pair_fn: Callable[[torch.Tensor, torch.Tensor], to
             else:
                 mids[j] = m
         pending += gather_step(j)
-        mids.pop(j - 1, None)  # its send was issued one step ago; the allocator keeps it alive
+        mids.pop(j - 1, None)  # its send was issued one step ago (and record_stream-ed on the comm stream)
     st.finish(pending)
+    if st.cuda:  # the rings go back to the allocator of the stream that is current here (compute)
+        for t in (recv_ring or []):
+            t.record_stream(st.comm)
+        for d in (stage_ring or []):
+            for t in d.values():
+                t.record_stream(st.comm)
     return out if is_root else None

@@ -21,6 +21,9 @@ Extra objects on that line:
   parity        -- PSNR of the HIP path and of the CPU oracle against a TRUE middle frame on a
                    checkpoint that interpolates (north_star: within 0.05 dB), and the raw bf16 error
                    of the bench's own random network.
+  fp32          -- the reference's own precision (N = 1): BASELINE configs[1] (batch 16 of 256x256 pairs,
+                   10 warm-up + 50 timed) and batch 4 of 1080p pairs, HIP-event timed, each with the
+                   roofline of its dominant kernel against the fp32 MFMA peak (157.3 TFLOP/s).
   video_sharded -- BASELINE configs[3]: a synthetic 1080p uint8 video held by rank 0, factor 2,
                    end to end through video.interpolate_video_sharded (RCCL send/recv scatter of
                    frame sub-batches, forward_u8, gather), beside the replicas-only `value`.
@@ -282,8 +285,18 @@ def video_leg(model, dev, dist, rank, world, n_frames, batch, h, w):
         for i in (0, (n_frames - 1) // 2, n_frames - 2):
             mid = model.forward_u8(frames[i][None, None], frames[i + 1][None, None])[0, 0]
             ok = ok and bool(torch.equal(res[2 * i + 1], mid)) and bool(torch.equal(res[2 * i], frames[i]))
+    seen = world
+    if dist is not None:  # ranks that actually answered on the RCCL communicator, and what each forwarded
+        cnt = torch.tensor([V.partition_pairs(n_frames, world)[rank][1]], device=dev, dtype=torch.int64)
+        allc = [torch.zeros_like(cnt) for _ in range(world)]
+        dist.all_gather(allc, cnt)
+        pairs_per_rank = [int(c.item()) for c in allc]
+        seen = dist.get_world_size()
+    else:
+        pairs_per_rank = [n_frames - 1]
     return {"frames_in": n_frames, "frames_out": 2 * n_frames - 1, "seconds": round(dt, 4),
-            "interpolated_frames_per_s": round((n_frames - 1) / dt, 2), "ranks": world,
+            "interpolated_frames_per_s": round((n_frames - 1) / dt, 2), "ranks": seen,
+            "pairs_per_rank": pairs_per_rank,
             "backend": "rccl (torch.distributed nccl) send/recv" if dist is not None else "single process",
             "sub_batch_pairs": batch, "spot_check_equal_to_single_gpu": ok,
             "note": "end to end: frames resident in rank 0's HBM -> interleaved uint8 result in rank 0's HBM"}
@@ -408,7 +421,7 @@ def main():
                     print(json.dumps(headline(args, world, elapsed, rows, nfw, default_workload,
                                               video_res, None, None, None)))
                     sys.stdout.flush()
-                os._exit(0)
+                os._exit(3)  # the headline is printed, but a hung leg must show in the return code
     if dist is not None and world >= 2 and default_workload and not args.no_tile4k:
         with _quiet_native_stdout():
             tile_res, err = _run_bounded(lambda: tile4k_leg(model, dev, dist, rank, world, 10), 120.0)
@@ -419,23 +432,80 @@ def main():
                     print(json.dumps(headline(args, world, elapsed, rows, nfw, default_workload,
                                               video_res, tile_res, None, None)))
                     sys.stdout.flush()
-                os._exit(0)
+                os._exit(3)
 
     if rank != 0:
         if dist is not None:
             dist.destroy_process_group()
         return
 
-    cpu_baseline = parity = None
+    cpu_baseline = parity = fp32 = None
+    if world == 1 and default_workload:
+        fp32 = fp32_legs(dev)
     if world == 1 and not args.no_cpu_baseline:
         cpu_baseline, parity = cpu_legs(dev, args.precision)
     print(json.dumps(headline(args, world, elapsed, rows, nfw, default_workload, video_res, tile_res,
-                              cpu_baseline, parity)))
+                              cpu_baseline, parity, fp32)))
     if dist is not None:
         dist.destroy_process_group()
 
 
-def headline(args, world, elapsed, rows, nfw, default_workload, video_res, tile_res, cpu_baseline, parity):
+def dominant_kernel(rows, precision):
+    """Stage rows (kernel name, avg ms, algorithmic FLOPs) grouped by kernel instantiation -> the
+    instantiation with the most time and its algorithmic FLOP rate."""
+    groups = {}
+    for name, ms, fl in rows:
+        g = groups.setdefault(name, {"ms": 0.0, "flops": 0.0, "launches": 0})
+        g["ms"] += ms; g["flops"] += fl; g["launches"] += 1
+    dom_name, dom = max(groups.items(), key=lambda kv: kv[1]["ms"])
+    achieved = dom["flops"] / (dom["ms"] * 1e-3) / 1e12 if dom["ms"] > 0 else 0.0
+    return dom_name, dom, achieved
+
+
+def fp32_legs(dev):
+    """The reference's own arithmetic (fp32) on the driver-timed line: BASELINE configs[1] (batch 16 of
+    256x256 pairs, SURVEY 8d config 2 protocol: 10 warm-up + 50 timed, HIP events around the forwards on
+    the launch stream, inputs resident) and batch 4 of 1080p pairs (1 warm-up + 5 timed), each with the
+    roofline of its dominant kernel against the fp32 MFMA peak.  ~3 s."""
+    model = make_bench_model("fp32").to(dev).eval()
+    out = {}
+    for key, b, h, w, warm, steps in (("config2_b16_256x256", 16, 256, 256, 10, 50),
+                                      ("b4_1080p", 4, 1080, 1920, 1, 5)):
+        gen = torch.Generator(device=dev).manual_seed(1)
+        f1 = torch.rand(b, 1, h, w, device=dev, generator=gen) * 2 - 1
+        f2 = torch.rand(b, 1, h, w, device=dev, generator=gen) * 2 - 1
+        for _ in range(warm):
+            model(f1, f2)
+        model._ctx.profile_enable(True)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        torch.cuda.synchronize()
+        e0.record()
+        for _ in range(steps):
+            model(f1, f2)
+        e1.record()
+        torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1) / steps
+        nfw, rows = model._ctx.profile_read()
+        model._ctx.profile_enable(False)
+        fps = b / (ms * 1e-3)
+        name, dom, ach = dominant_kernel(rows, "fp32")
+        peak = PEAK_TFLOPS["fp32"]
+        out[key] = {
+            "value": round(fps, 2), "unit": "frames/s", "ms_per_step": round(ms, 4), "steps": steps, "warmup": warm,
+            "dtype": "fp32", "workload": f"batch={b} {w}x{h} synthetic frame pairs, exact-fp32 MFMA conv path",
+            "roofline": {"bound": "mfma", "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s",
+                         "frac": round(ach / peak, 4), "kernel": name, "launches_per_step": dom["launches"],
+                         "avg_launch_ms": round(dom["ms"] / dom["launches"], 4),
+                         "algorithmic_flops_per_launch": dom["flops"] / dom["launches"], "traffic": None,
+                         "whole_forward_tflops": round(fps * conv_flops(h, w) / 1e12, 2),
+                         "whole_forward_mfma_frac": round(fps * conv_flops(h, w) / 1e12 / peak, 4)},
+        }
+        del f1, f2
+    return out
+
+
+def headline(args, world, elapsed, rows, nfw, default_workload, video_res, tile_res, cpu_baseline, parity,
+             fp32=None):
     b, h, w = args.batch, args.height, args.width
     fps = world * b * args.steps / elapsed
     ms_step = elapsed / args.steps * 1e3
@@ -443,13 +513,8 @@ def headline(args, world, elapsed, rows, nfw, default_workload, video_res, tile_
     es = 2 if args.precision == "bf16" else 4
 
     # ---- roofline of the dominant kernel (grouped by kernel instantiation) ------------------
-    groups = {}
-    for name, ms, fl in rows:
-        g = groups.setdefault(name, {"ms": 0.0, "flops": 0.0, "launches": 0})
-        g["ms"] += ms; g["flops"] += fl; g["launches"] += 1
-    dom_name, dom = max(groups.items(), key=lambda kv: kv[1]["ms"])
+    dom_name, dom, achieved = dominant_kernel(rows, args.precision)
     peak = PEAK_TFLOPS[args.precision]
-    achieved = dom["flops"] / (dom["ms"] * 1e-3) / 1e12 if dom["ms"] > 0 else 0.0
     traffic = traffic_source = None
     pmc = os.path.join(ROOT, "profiles", "pmc_summary.json")
     if os.path.exists(pmc) and default_workload:  # the committed PMC pass is of this workload only
@@ -495,6 +560,8 @@ def headline(args, world, elapsed, rows, nfw, default_workload, video_res, tile_
         result["cpu_baseline"] = cpu_baseline
     if parity is not None:
         result["parity"] = parity
+    if fp32 is not None:
+        result["fp32"] = fp32
     if video_res is not None:
         result["video_sharded"] = video_res
     if tile_res is not None:

@@ -21,7 +21,7 @@
 extern "C" {
 #endif
 
-#define FIUNET_ABI_VERSION 2
+#define FIUNET_ABI_VERSION 3
 
 enum fiunet_status {
     FIUNET_OK = 0,
@@ -47,6 +47,13 @@ enum fiunet_option {
                                head otherwise keeps in registers; for fiunet_debug_read_activation */
     FIUNET_OPT_PAIR_TILES = 8, /* A/B runs: direct >=128-channel convs on the 8-wave tile-pair kernel
                                (conv3x3_pair.hip.h: shared weight ring, double-buffered in-tile); same bits */
+    FIUNET_OPT_RNE_WEIGHTS = 32, /* A/B runs: round the bf16 conv weights to nearest instead of with the per-filter
+                               error feedback (fiunet.hip, f32_to_bf16_feedback).  Read by fiunet_load_weights: set it
+                               BEFORE loading */
+    FIUNET_OPT_NO_DITHER = 64, /* A/B runs: switch off the ordered input dither of the bf16 stem (+-2^-9 on the
+                               frames, +d on frame 1 / -d on frame 2, an 8x8 Bayer pattern of the global pixel
+                               position: it decorrelates the bf16 rounding of values the network carries through
+                               its full-resolution skip from the image content; conv3x3_mfma.hip.h, stem_dither) */
     FIUNET_OPT_GATHER_UPSAMPLE = 16 /* A/B runs and tests: always interpolate the upsampled half of a concat
                                input inside the conv's gather; by default the bf16 convs with >= 2 cout tiles
                                on >= 64k pixels read it from a tensor written once by upsample_kernel; same bits */
@@ -132,6 +139,22 @@ int fiunet_psnr_u8(const uint8_t* pred, const uint8_t* target, int images, int H
                    void* workspace, size_t workspace_bytes, void* stream);
 int fiunet_ssim_u8(const uint8_t* pred, const uint8_t* target, int images, int H, int W, double* out,
                    void* workspace, size_t workspace_bytes, void* stream);
+
+/* The training loss' SSIM on device: SSIMLoss._ssim (model/train.py:37-56) - the
+ * window_size x window_size Gaussian window (sigma 1.5, normalised as at train.py:27-35) applied as a
+ * depth-wise conv2d with ZERO padding window_size//2 to img1, img2, img1^2, img2^2, img1*img2;
+ * C1 = 0.01^2, C2 = 0.03^2; mean of the map.  img1, img2: device fp32, `images` planes of H x W (a
+ * [B, C, H, W] tensor is B*C planes: the conv is depth-wise, so planes are independent), in the caller's
+ * value range.  out_ssim: device double[images], the mean of each plane's SSIM map (all planes have H*W
+ * pixels, so `ssim_map.mean()` (:54) is the mean of these and `.mean(1).mean(1).mean(1)` (:56) the mean
+ * over a sample's C planes).  out_sqerr (may be NULL): device double[images], sum (img1 - img2)^2 of each
+ * plane - CombinedLoss' MSE term (train.py:75-87) is their total / (images*H*W).  window_size must be odd
+ * (the reference's default and only value is 11) and <= 31.  Workspace:
+ * fiunet_ssim_gauss_workspace_bytes(images, H, W), 256-B aligned.  Asynchronous on `stream`. */
+size_t fiunet_ssim_gauss_workspace_bytes(int images, int H, int W);
+int fiunet_ssim_gauss_f32(const float* img1, const float* img2, int images, int H, int W, int window_size,
+                          double* out_ssim, double* out_sqerr, void* workspace, size_t workspace_bytes,
+                          void* stream);
 
 /* Parity-test hook: after a fiunet_forward on `workspace`, convert one intermediate activation
  * (NHWC in the compute precision) to fp32 NCHW at dst.  tap = 2*block + conv for the 18 fused

@@ -71,7 +71,72 @@ def gen_rgb():
                             out=out.numpy())
 
 
+SSIM_CASES = (  # name, seed, B, C, H, W, value range, noise
+    ("b1c1_32x48", 41, 1, 1, 32, 48, "unit", 0.05),
+    ("b2c1_64x64", 42, 2, 1, 64, 64, "unit", 0.10),
+    ("b1c3_33x47", 43, 1, 3, 33, 47, "unit", 0.05),     # odd sizes, C = 3 (window rebuilt, train.py:59-70)
+    ("b3c3_17x31", 44, 3, 3, 17, 31, "sym", 0.20),      # [-1, 1] tensors (inference normalisation)
+    ("b1c1_7x9", 45, 1, 1, 7, 9, "unit", 0.10),         # smaller than the 11x11 window: all padding
+    ("b1c1_256x256", 46, 1, 1, 256, 256, "unit", 0.02),  # the reference's training size
+    ("b2c1_135x240", 47, 2, 1, 135, 240, "unit", 0.30),  # spans several 64x16 tiles, ragged edges
+)
+
+
+def make_ssim_pair(seed, b, c, h, w, rng_kind, noise):
+    """Smooth structure + noise (so the variance terms are neither 0 nor dominated by noise)."""
+    g = torch.Generator().manual_seed(seed)
+    ys = torch.linspace(0, 3.0, h).view(1, 1, h, 1)
+    xs = torch.linspace(0, 4.0, w).view(1, 1, 1, w)
+    ph = torch.rand(b, c, 1, 1, generator=g) * 6.28
+    base = 0.5 + 0.35 * torch.sin(2.1 * ys + ph) * torch.cos(1.7 * xs - ph)
+    img1 = (base + 0.08 * torch.rand(b, c, h, w, generator=g)).clamp(0, 1)
+    img2 = (img1 + noise * (torch.rand(b, c, h, w, generator=g) - 0.5)).clamp(0, 1)
+    if rng_kind == "sym":
+        img1, img2 = img1 * 2 - 1, img2 * 2 - 1
+    return img1.float().contiguous(), img2.float().contiguous()
+
+
+def gen_ssim():
+    """Gaussian-window SSIM / CombinedLoss fixtures from the reference's own classes (train.py:18-87).
+    `train.py` imports cv2 at module level (train.py:7) but neither class touches it; cv2 is not
+    installed in this image, so an EMPTY placeholder module is registered for the duration of the import
+    (nothing in it is ever called; the values below come from torch ops alone)."""
+    import types
+    sys.path.insert(0, REF_DIR)
+    placeholder = "cv2" not in sys.modules
+    if placeholder:
+        try:
+            import cv2  # noqa: F401
+            placeholder = False
+        except ImportError:
+            sys.modules["cv2"] = types.ModuleType("cv2")
+    import train as ref_train  # the reference module (train.py)
+    if placeholder:
+        del sys.modules["cv2"]
+    torch.set_num_threads(8)
+    from oracle import metrics_oracle as MO
+    for name, seed, b, c, h, w, kind, noise in SSIM_CASES:
+        img1, img2 = make_ssim_pair(seed, b, c, h, w, kind, noise)
+        with torch.no_grad():
+            loss_avg = ref_train.SSIMLoss()(img1, img2)                       # 1 - ssim_map.mean()
+            loss_per = ref_train.SSIMLoss(size_average=False)(img1, img2)     # [B]
+            comb = ref_train.CombinedLoss()(img1, img2)
+            mse = torch.nn.MSELoss()(img1, img2)
+        mine = MO.ssim_gauss(img1, img2)
+        mine64 = MO.ssim_gauss(img1, img2, dtype=torch.float64)
+        print(f"ssim {name}: ssim {1 - loss_avg.item():.7f} combined {comb.item():.7f} "
+              f"|restatement-ref| {abs((1 - loss_avg.item()) - mine.item()):.2e} "
+              f"|fp64 restatement-ref| {abs((1 - loss_avg.item()) - mine64.item()):.2e}")
+        np.savez_compressed(os.path.join(GOLD, f"ssim_gauss_{name}.npz"), seed=seed, img1=img1.numpy(),
+                            img2=img2.numpy(), ssim_loss=np.float32(loss_avg.item()),
+                            ssim_loss_per_sample=loss_per.numpy(), combined_loss=np.float32(comb.item()),
+                            mse=np.float32(mse.item()))
+
+
 def main():
+    if "--ssim-only" in sys.argv:
+        os.makedirs(GOLD, exist_ok=True)
+        return gen_ssim()
     if "--rgb-only" in sys.argv:  # add the RGB fixtures without re-recording the others
         os.makedirs(GOLD, exist_ok=True)
         return gen_rgb()
@@ -190,6 +255,7 @@ def main():
     np.savez_compressed(os.path.join(GOLD, "post_b1_64x64.npz"),
                         out=out.numpy(), u8=u8, gt_u8=gt, psnr=np.float64(O.psnr_u8(gt, u8)))
     gen_rgb()
+    gen_ssim()
     print("done; files:", sorted(os.listdir(GOLD)))
 
 

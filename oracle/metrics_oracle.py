@@ -12,11 +12,60 @@ uniform filter = scipy.ndimage.uniform_filter, use_sample_covariance=True, K1 0.
 the map cropped by (win_size-1)//2) and is pinned only by `ssim_bruteforce` below, an independent
 pure-Python evaluation of the SSIM definition on small images: **parity unpinned against skimage
 itself**.  Only tests/ may import this module.
+
+`ssim_gauss` / `combined_loss` restate the reference's OTHER SSIM, the pure-torch Gaussian-window one of
+its training loss (/root/reference/model/train.py:18-87).  That one IS pinned: oracle/gen_golden.py
+(`--ssim-only`) imports the real `train.SSIMLoss` / `train.CombinedLoss` in the build container and records
+inputs + values in tests/golden/ssim_gauss_*.npz; tests/test_oracle.py checks this restatement against
+them.
 """
 from __future__ import annotations
 
 import numpy as np
 from scipy import ndimage
+
+
+def gauss_window(window_size: int = 11, sigma: float = 1.5, dtype=None):
+    """train.py:27-35: normalised fp32 1-D Gaussian -> [1, 1, ws, ws] outer product (fp32 product, as
+    the reference's `.mm`; with dtype=float64 the outer product of the SAME fp32 1-D values is taken in
+    double, which is what a separable evaluation with fp64 sums computes)."""
+    import torch
+    g = torch.tensor([float(np.exp(-(x - window_size // 2) ** 2 / float(2 * sigma ** 2)))
+                      for x in range(window_size)], dtype=torch.float32)
+    g = (g / g.sum()).unsqueeze(1)
+    if dtype is not None and dtype != torch.float32:
+        g = g.to(dtype)
+        return g.mm(g.t()).unsqueeze(0).unsqueeze(0)
+    return g.mm(g.t()).float().unsqueeze(0).unsqueeze(0)
+
+
+def ssim_gauss(img1, img2, window_size: int = 11, size_average: bool = True, dtype=None):
+    """SSIMLoss._ssim (train.py:37-56) on [B, C, H, W] torch CPU tensors: depth-wise conv2d with zero
+    padding window_size//2.  dtype=torch.float64 evaluates the same formula in double (the value the
+    device kernel, which sums in fp64, should sit next to)."""
+    import torch
+    import torch.nn.functional as F
+    c = img1.shape[1]
+    dt = dtype or img1.dtype
+    a, b = img1.to(dt), img2.to(dt)
+    win = gauss_window(window_size, dtype=dt).expand(c, 1, window_size, window_size).contiguous()
+    conv = lambda t: F.conv2d(t, win, padding=window_size // 2, groups=c)
+    mu1, mu2 = conv(a), conv(b)
+    mu1_sq, mu2_sq, mu1_mu2 = mu1 * mu1, mu2 * mu2, mu1 * mu2
+    # the products are fp32 tensors in the reference whatever the accumulation type
+    s1 = conv((img1 * img1).to(dt)) - mu1_sq
+    s2 = conv((img2 * img2).to(dt)) - mu2_sq
+    s12 = conv((img1 * img2).to(dt)) - mu1_mu2
+    c1, c2 = 0.01 ** 2, 0.03 ** 2
+    m = ((2 * mu1_mu2 + c1) * (2 * s12 + c2)) / ((mu1_sq + mu2_sq + c1) * (s1 + s2 + c2))
+    return m.mean() if size_average else m.mean(1).mean(1).mean(1)
+
+
+def combined_loss(pred, target, mse_weight: float = 0.5, ssim_weight: float = 0.5, dtype=None):
+    """CombinedLoss.forward (train.py:75-87)."""
+    dt = dtype or pred.dtype
+    mse = ((pred - target).to(dt) ** 2).mean()
+    return mse_weight * mse + ssim_weight * (1 - ssim_gauss(pred, target, dtype=dtype))
 
 
 def psnr_u8(pred: np.ndarray, target: np.ndarray) -> float:

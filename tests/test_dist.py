@@ -24,6 +24,31 @@ def _pair_fn(a, b):
     return ((a.to(torch.int32) + b.to(torch.int32) + 1) // 2).to(torch.uint8)
 
 
+def _links_agree(traces, n_frames, world, batch):
+    """Per link root<->r: the sequence of transfers root issued towards r is the mirror image (send <->
+    recv, same kind, sub-batch and frame count, same ORDER) of what r issued towards root - the property
+    that keeps the pipelined point-to-point schedule from deadlocking on an in-order transport - and
+    every sub-batch of every non-root rank crosses the link exactly once in each direction."""
+    flip = {"send": "recv", "recv": "send"}
+    parts = video.partition_pairs(n_frames, world)
+    for r in range(1, world):
+        root_side = [(op, kind, j, n) for op, peer, kind, j, n in traces[0] if peer == r]
+        peer_side = [(flip[op], kind, j, n) for op, peer, kind, j, n in traces[r] if peer == 0]
+        if root_side != peer_side:
+            return False
+        subs = video.sub_batches(parts[r][1], batch)
+        if sorted(x for x in root_side if x[1] == "scatter") != [("send", "scatter", j, c + 1) for j, (_, c) in enumerate(subs)]:
+            return False
+        if sorted(x for x in root_side if x[1] == "gather") != [("recv", "gather", j, c) for j, (_, c) in enumerate(subs)]:
+            return False
+        # a gather of sub-batch j is never issued before the scatter of j (+1 look-ahead at most)
+        order = [(kind, j) for _, kind, j, _ in root_side]
+        for j in range(len(subs)):
+            if order.index(("gather", j)) < order.index(("scatter", j)):
+                return False
+    return all(peer in (0,) for r in range(1, world) for _, peer, *_ in traces[r])
+
+
 def _worker(rank, world, port, n_frames, shape, q):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
@@ -31,14 +56,17 @@ def _worker(rank, world, port, n_frames, shape, q):
     try:
         g = torch.Generator().manual_seed(5)
         frames = torch.randint(0, 256, (n_frames,) + shape, dtype=torch.uint8, generator=g)
+        trace = []
         out = video.interpolate_video_sharded(_pair_fn, frames if rank == 0 else None, n_frames,
-                                              shape, torch.device("cpu"), batch=3)
+                                              shape, torch.device("cpu"), batch=3, trace=trace)
+        traces = [None] * world
+        dist.all_gather_object(traces, trace)
         if rank == 0:
             want = torch.empty((2 * n_frames - 1,) + shape, dtype=torch.uint8)
             want[0::2] = frames
             if n_frames > 1:
                 want[1::2] = _pair_fn(frames[:-1], frames[1:])
-            q.put(bool(torch.equal(out, want)))
+            q.put(bool(torch.equal(out, want)) and _links_agree(traces, n_frames, world, 3))
         else:
             assert out is None
     finally:

@@ -134,3 +134,82 @@ def test_evaluate_triplets_matches_host_scoring(seeded_sd):
         assert st["min_psnr"] == pytest.approx(ps.min(), abs=1e-9) and st["max_ssim"] == pytest.approx(ss.max(), abs=1e-9)
     with pytest.raises(NotImplementedError, match="OpenCV"):
         evaluation.evaluate_triplets(m, f0.to(dev), f1.to(dev), gt.to(dev), methods=("optical_flow",))
+
+
+# ---- Gaussian-window SSIM / CombinedLoss of the training loss (train.py:18-87) --------------------
+# Fixtures: oracle/gen_golden.py --ssim-only ran the reference's own SSIMLoss / CombinedLoss.
+GAUSS = ["b1c1_32x48", "b2c1_64x64", "b1c3_33x47", "b3c3_17x31", "b1c1_7x9", "b1c1_256x256", "b2c1_135x240"]
+
+
+def _gauss_fixture(golden_dir, name):
+    import os
+    g = np.load(os.path.join(golden_dir, f"ssim_gauss_{name}.npz"))
+    return (torch.from_numpy(g["img1"]), torch.from_numpy(g["img2"]), float(g["ssim_loss"]),
+            g["ssim_loss_per_sample"], float(g["combined_loss"]), float(g["mse"]))
+
+
+@pytest.mark.parametrize("name", GAUSS)
+def test_oracle_gauss_ssim_equals_reference(golden_dir, name):
+    """The restatement against the values the reference's own classes produced (fp32: same aten ops, so
+    only thread-count-dependent summation order can differ)."""
+    torch.set_num_threads(8)
+    a, b, loss, per, comb, mse = _gauss_fixture(golden_dir, name)
+    assert float(1 - M.ssim_gauss(a, b)) == pytest.approx(loss, abs=2e-6)
+    assert np.allclose((1 - M.ssim_gauss(a, b, size_average=False)).numpy(), per, atol=2e-6)
+    assert float(M.combined_loss(a, b)) == pytest.approx(comb, abs=2e-6)
+    # evaluated in double the formula sits within fp32 rounding of the reference's value
+    assert float(1 - M.ssim_gauss(a, b, dtype=torch.float64)) == pytest.approx(loss, abs=5e-6)
+    # identical images: ssim == 1 up to rounding; the window is normalised
+    assert float(M.ssim_gauss(a, a)) == pytest.approx(1.0, abs=1e-6)
+    assert float(M.gauss_window().sum()) == pytest.approx(1.0, abs=1e-6)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", GAUSS)
+def test_device_gauss_ssim_matches_reference_fixtures(golden_dir, name):
+    """The HIP kernel against the reference's own SSIMLoss / CombinedLoss values: <= 1e-5."""
+    from ai_based_frame_interpolation_amd import metrics
+    dev = torch.device("cuda:0")
+    a, b, loss, per, comb, mse = _gauss_fixture(golden_dir, name)
+    A, B = a.to(dev), b.to(dev)
+    got = metrics.SSIMLoss()(A, B)
+    assert got.dtype == torch.float32 and got.dim() == 0
+    assert float(got) == pytest.approx(loss, abs=1e-5)
+    got_per = metrics.SSIMLoss(size_average=False)(A, B).cpu().numpy()
+    assert got_per.shape == per.shape and np.allclose(got_per, per, atol=1e-5)
+    assert float(metrics.CombinedLoss()(A, B)) == pytest.approx(comb, abs=1e-5)
+    m, s = metrics.CombinedLoss().terms(A, B)
+    assert float(m) == pytest.approx(mse, rel=1e-5, abs=1e-8)
+    # fp64 device value vs the oracle's fp64 evaluation of the same formula: 1e-9
+    v64 = float(metrics.ssim_gauss(A, B, dtype=torch.float64))
+    assert v64 == pytest.approx(float(M.ssim_gauss(a, b, dtype=torch.float64)), abs=1e-9)
+    assert float(s) == v64
+    # deterministic, symmetric, 1 on identical inputs
+    assert float(metrics.ssim_gauss(A, B, dtype=torch.float64)) == v64
+    assert float(metrics.ssim_gauss(B, A, dtype=torch.float64)) == pytest.approx(v64, abs=1e-12)
+    assert float(metrics.ssim_gauss(A, A, dtype=torch.float64)) == pytest.approx(1.0, abs=1e-12)
+
+
+@pytest.mark.gpu
+def test_device_gauss_ssim_full_size_and_errors():
+    from ai_based_frame_interpolation_amd import metrics
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(9)
+    a = torch.rand(2, 1, 1080, 1920, generator=g)
+    b = (a + 0.1 * (torch.rand(2, 1, 1080, 1920, generator=g) - 0.5)).clamp(0, 1)
+    torch.set_num_threads(16)
+    ref = M.ssim_gauss(a, b, size_average=False, dtype=torch.float64).numpy()
+    got = metrics.ssim_gauss(a.to(dev), b.to(dev), size_average=False, dtype=torch.float64).cpu().numpy()
+    assert np.allclose(got, ref, atol=1e-9)
+    # other odd windows run the generic-radius kernel
+    for ws in (3, 7, 15):
+        r = float(M.ssim_gauss(a[:, :, :70, :90], b[:, :, :70, :90], window_size=ws, dtype=torch.float64))
+        d = float(metrics.ssim_gauss(a[:, :, :70, :90].to(dev), b[:, :, :70, :90].to(dev), window_size=ws,
+                                     dtype=torch.float64))
+        assert d == pytest.approx(r, abs=1e-9)
+    with pytest.raises(RuntimeError, match="odd"):
+        metrics.ssim_gauss(a.to(dev), b.to(dev), window_size=10)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        metrics.ssim_gauss(a, b)
+    with pytest.raises(RuntimeError, match="fp32"):
+        metrics.ssim_gauss(a.to(dev).double(), b.to(dev).double())
