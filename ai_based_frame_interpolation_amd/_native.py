@@ -59,6 +59,21 @@ def lib() -> ctypes.CDLL:
             "(run `python -c 'import __graft_entry__ as g; g.build()'` or `make -C "
             f"{CSRC}`).  There is no CPU fallback for this path.")
     L = ctypes.CDLL(LIB_PATH)
+    if os.environ.get("FIUNET_LIB"):
+        # an A/B build of an older source state (tools/ab_bench.py) may predate the newest entry points:
+        # bind what it has; calling a missing one still fails loudly (AttributeError)
+        have = [n for n in SYMBOLS if hasattr(L, n)]
+        if len(have) != len(SYMBOLS):
+            class _Partial:
+                def __init__(self, lib): self.__dict__["_lib"] = lib
+                def __getattr__(self, n):
+                    if n in SYMBOLS and n not in have:
+                        class _Missing:
+                            def __setattr__(self, *a): pass
+                            def __call__(self, *a): raise AttributeError(f"{LIB_PATH} does not export {n}")
+                        return _Missing()
+                    return getattr(self._lib, n)
+            L = _Partial(L)
     vp, ci, sz = ctypes.c_void_p, ctypes.c_int, ctypes.c_size_t
     L.fiunet_abi_version.restype = ci
     L.fiunet_last_error_string.restype = ctypes.c_char_p
@@ -84,12 +99,13 @@ def lib() -> ctypes.CDLL:
     L.fiunet_ssim_u8.argtypes = [vp, vp, ci, ci, ci, vp, vp, sz, vp]
     L.fiunet_ssim_gauss_workspace_bytes.argtypes = [ci, ci, ci]
     L.fiunet_ssim_gauss_workspace_bytes.restype = sz
-    L.fiunet_ssim_gauss_f32.argtypes = [vp, vp, ci, ci, ci, ci, vp, vp, vp, sz, vp]
+    L.fiunet_ssim_gauss_f32.argtypes = [vp, vp, ci, ci, ci, ci, vp, vp, vp, vp, sz, vp]
     L.fiunet_profile_enable.argtypes = [vp, ci]
     L.fiunet_profile_read.argtypes = [vp, ctypes.POINTER(ci), ctypes.POINTER(ctypes.c_float),
                                       ctypes.POINTER(ctypes.c_double), ctypes.c_char_p, ci]
-    for name in SYMBOLS:
-        getattr(L, name)  # AttributeError here = the .so does not export what the header declares
+    if not os.environ.get("FIUNET_LIB"):
+        for name in SYMBOLS:
+            getattr(L, name)  # AttributeError here = the .so does not export what the header declares
     _lib = L
     return L
 

@@ -100,6 +100,11 @@ struct ConvArgs {
     const float* head_w; // fused 1x1 head: [head_nc][64]
     const float* head_b; // [head_nc]
     float* head_out;     // fp32 NCHW [B][head_nc][H][W]
+    // fiunet_forward_u8: the reference's pre/post-processing (model/inference.py:31-35, :54-61) applied where the
+    // frames are read and where the output is written, so no fp32 frame buffer exists
+    const uint8_t* u1;        // SRC_STEM: uint8 frames [B][1][H][W] instead of f1 / f2 (nullptr: fp32 frames)
+    const uint8_t* u2;
+    uint8_t* head_out_u8;     // fused head: uint8 NCHW output instead of head_out (nullptr: fp32 logits)
     int head_nc;
 };
 
@@ -235,6 +240,25 @@ __device__ __forceinline__ uint4 chunk_vlerp(const float* top, const float* bot,
 }
 
 __device__ __forceinline__ uint4 ldg16(const char* p) { return *reinterpret_cast<const uint4*>(p); }
+
+// model/inference.py:31-35: image.astype(float32) / 255.0 ; 2.0 * image - 1.0   (numpy fp32 arithmetic)
+__device__ __forceinline__ float preprocess_u8_value(unsigned char u)
+{
+    // u / 255 correctly rounded without the division sequence: q0 = u * RN(1/255), one Newton correction
+    // with the exact remainder (fma); equal to the IEEE quotient for all 256 codes (asserted bit for bit
+    // against numpy by tests/test_gpu_parity.py over every code)
+    const float x = (float)u, r = 1.0f / 255.0f;
+    const float q0 = __fmul_rn(x, r);
+    const float q = fmaf(fmaf(-q0, 255.0f, x), r, q0);
+    return __fsub_rn(__fmul_rn(2.0f, q), 1.0f);
+}
+// model/inference.py:54-61: (x + 1) / 2 ; clamp(0, 1) ; (x * 255).astype(uint8) -- truncation
+__device__ __forceinline__ unsigned char postprocess_u8_value(float x)
+{
+    float v = __fdiv_rn(__fadd_rn(x, 1.0f), 2.0f);
+    v = fminf(fmaxf(v, 0.0f), 1.0f);
+    return (unsigned char)(int)__fmul_rn(v, 255.0f);
+}
 
 // Ordered dither of the bf16 path's INPUT (bf16 stem only; the fp32 path never sees it).
 // Why: a bf16 activation has 8 significant bits, the frames have 8 too (x = 2*u8/255 - 1), and a network
@@ -438,21 +462,26 @@ template <int BN, int TH, int TW, int MODE> struct ConvTile {
     static constexpr int SPARE_BYTES =
         (MODE == SRC_CONCAT_UP && LR_PIECES * 1024 > W_BYTES) ? LR_PIECES * 1024 - W_BYTES : 0;
     static constexpr int W_STRIDE = W_BYTES + SPARE_BYTES;  // slot 1 = slot 0 + W_STRIDE
-    // SRC_STEM: raw patch of both frames, (TH+4) x (TW+4) pixels, after the ring.  Row pitch PATCH_W
-    // pixels (= dwords) with 2 * PATCH_W = 16 (mod 32): the fragment reads are ds_read2_b32 (32 banks,
-    // lanes 0-31 together), lane groups 0 / 1 read patch rows py / py+2, so their 16 dwords each land in
-    // complementary bank halves (a pitch of TW+4 = 36 made them overlap in 8 banks: 2-way conflicts)
-    static constexpr int PATCH_W = TW + 8, PATCH_H = TH + 4;
-    static_assert(MODE != SRC_STEM || (2 * PATCH_W) % 32 == 16, "patch pitch: lane groups 0/1 must not share banks");
+    // SRC_STEM: raw patch of both frames, (TH+4) x (TW+4) pixels, after the ring: bf16 dwords {frame1,
+    // frame2}, the hi and the lo part of a patch row side by side, [row][hi | lo][PATCH_W].  The row pitch
+    // of 2 * PATCH_W = 72 dwords makes rows py and py+2 - read together by lane groups 0 and 1 of a
+    // ds_read2_b32 (lanes 0-31, 32 banks) - sit 144 = 16 (mod 32) banks apart: no conflicts (separate hi
+    // and lo images of pitch 36 put rows py, py+1 only 4 banks apart: 2-way conflicts on 12 of 16 lanes).
+    static constexpr int PATCH_W = TW + 4, PATCH_H = TH + 4, PATCH_PITCH = 2 * PATCH_W;
+    static_assert(MODE != SRC_STEM || (2 * PATCH_PITCH) % 32 == 16, "patch pitch: lane groups 0/1 must not share banks");
     static constexpr int PATCH_OFF = IN_BYTES + 2 * W_BYTES + SPARE_BYTES;
-    // two bf16 images (hi, lo) of [PATCH_H][PATCH_W][2 frames], each followed by a 36-dword tail
-    // (hi: dwords {1.0, 0}, the operand of the bias k-slot; lo: zeros) that lane group 3 reads at a
-    // bank offset 16 away from lane group 2's dwords
-    static constexpr int PATCH_TAIL = 144;
-    static constexpr int PATCH_BYTES = MODE == SRC_STEM ? 2 * (PATCH_H * PATCH_W * 4 + PATCH_TAIL) : 0;
+    // The operand of the bias k-slot - PATCH_W dwords {1.0, 0} followed by PATCH_W zero dwords (its lo
+    // part), which all lanes of lane group 3 read at the same address (a broadcast) - lives in the
+    // row-pitch filler of in-tile row 0 (pixels TW+2 .. TWP-1: never written or read in this mode), so
+    // that the workgroup stays at 63 LDS allocation granules of 1280 B: at 64 (= 80 KiB, two workgroups
+    // filling the CU's LDS exactly) this kernel ran 5 % slower.
+    static constexpr int PATCH_TAIL_OFF = (TW + 2) * 64;                 // byte offset inside the in-tile
+    static constexpr int PATCH_TAIL = 2 * PATCH_W * 4;
+    static_assert(MODE != SRC_STEM || PATCH_TAIL_OFF + PATCH_TAIL <= TWP * 64, "bias operand must fit the row-pitch filler");
+    static constexpr int PATCH_BYTES = MODE == SRC_STEM ? PATCH_H * PATCH_PITCH * 4 : 0;
     // CONCAT_UP: the bilinear mapping of this tile, one 16-B entry per in-tile row and per in-tile
     // pixel column (same for every plane, so it is evaluated once per tile, not per plane)
-    static constexpr int TAB_OFF = PATCH_OFF + ((PATCH_BYTES + 255) / 256) * 256;
+    static constexpr int TAB_OFF = PATCH_OFF + ((PATCH_BYTES + 15) / 16) * 16;
     static constexpr int TAB_BYTES = MODE == SRC_CONCAT_UP ? ((THP + TW + 2) * 16 + 255) / 256 * 256 : 0;
     // SRC_STEM: plane 1's stem weights (hi and lo halves of two 16-cout tiles), parked here by
     // LDS-DMA at kernel start so the plane boundary does not wait on a global load
@@ -460,6 +489,7 @@ template <int BN, int TH, int TW, int MODE> struct ConvTile {
     static constexpr int STEMW_BYTES = MODE == SRC_STEM ? 4096 : 0;
     static constexpr int LDS_BYTES = STEMW_OFF + STEMW_BYTES;
     static_assert(LDS_BYTES <= 80 * 1024, "two workgroups must fit in the CU's 160 KiB of LDS");
+    static_assert(MODE != SRC_STEM || LDS_BYTES <= 63 * 1280, "fused-stem kernel: stay below 64 LDS granules");
 };
 
 // 16-pixel fragments per wave: 8 (wave tile 64 couts x 128 pixels, 128 accumulator registers, two
@@ -600,7 +630,11 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x4 (&acc)[4]
                 const int n = nb + j;
                 const int y = y0 + wp * ROWS_W + n / FR;
                 const int x = x0 + (n % FR) * 16 + l15;
-                if (y < aH && x < aW) a.head_out[(((size_t)b * HNC + c) * aH + y) * aW + x] = u[j] + hb[c];
+                if (y < aH && x < aW) {
+                    const size_t o = (((size_t)b * HNC + c) * aH + y) * aW + x;
+                    if (a.head_out_u8) a.head_out_u8[o] = postprocess_u8_value(u[j] + hb[c]);
+                    else a.head_out[o] = u[j] + hb[c];
+                }
             }
         }
     }
@@ -1028,40 +1062,66 @@ __global__ __launch_bounds__(256, conv_occupancy(BN, TH, TW)) void conv3x3_mfma_
     //      xh*wh + xl*wh + xh*wl, fp32 accumulate) keeps ~2^-16 relative accuracy, far below the
     //      bf16 rounding of the result.  k = tap*2 + frame (18 of 32 slots used).
     constexpr int NIN = THP * (TW + 2);  // in-tile pixels
-    // patch image: bf16, [hi | lo][row][col][frame]; the 8 k-slots of lane group dy are then the 16
-    // contiguous bytes (4 columns x 2 frames) at (row + dy, col): k = dy*8 + dx*2 + frame, with zero
-    // weights for dx = 3 and dy = 3.
+    // patch image: bf16, [row][hi | lo][col][frame]; the 8 k-slots of a lane group are the 16 contiguous
+    // bytes (4 columns x 2 frames) at (row + dy, col): k = lane group*8 + dx*2 + frame, zero weights for dx = 3.
     char* const patch = smem + Tile::PATCH_OFF;
-    constexpr int PW = Tile::PATCH_W, PH = Tile::PATCH_H;
-    constexpr int PATCH_HALF = Tile::PATCH_BYTES / 2;  // bytes of the hi (or lo) image incl. pad
+    constexpr int PW = Tile::PATCH_W, PH = Tile::PATCH_H, PP = Tile::PATCH_PITCH;
     auto stage_patch = [&]() __attribute__((always_inline)) {
         if constexpr (MODE == SRC_STEM) {
-            unsigned short* const ph = reinterpret_cast<unsigned short*>(patch);
-            unsigned short* const pl = reinterpret_cast<unsigned short*>(patch + PATCH_HALF);
-            constexpr int NE = PATCH_HALF / 2;        // elements incl. the tail
-            constexpr int NB = (NE + 255) / 256;      // all loads are issued before the first use
-            float v[NB];
+            // one thread = one patch pixel (both frames): one address, one dither value, one dword store
+            // for the hi pair and one for the lo pair (the prologue is VALU-bound: SQ_INSTS_VALU per wave
+            // tracks its time, profiles/r03_pmc_ab_stem.txt)
+            unsigned* const pd = reinterpret_cast<unsigned*>(patch);  // dwords {frame1, frame2}; lo part: + PW
+            constexpr int NP = PH * PW;               // patch pixels
+            constexpr int NB = (NP + 255) / 256;      // all loads are issued before the first use
+            float v0[NB], v1[NB];
+            unsigned okm = 0;
+            // unconditional loads from clamped coordinates (all issued back to back, one wait), the
+            // out-of-image pixels are zeroed afterwards
+            size_t at[NB];
 #pragma unroll
             for (int k = 0; k < NB; ++k) {
-                const int i = tid + k * 256;
-                const int f = i & 1, r = i >> 1;
+                const int r = tid + k * 256;
                 const int py = r / PW, px = r - py * PW;
                 const int y = y0 - 2 + py, x = x0 - 2 + px;
-                const bool ok = (i < NE) & (py < PH) & (y >= 0) & (y < aH) & (x >= 0) & (x < aW);
-                const float* src = f ? a.f2 : a.f1;
-                v[k] = ok ? src[((size_t)b * aH + (ok ? y : 0)) * aW + (ok ? x : 0)] : 0.f;
-                // ordered input dither, +d on frame 1 and -d on frame 2 (stem_dither); the conv's zero
-                // padding stays exactly zero
-                if (ok) v[k] = v[k] + (f ? -a.dither : a.dither) * stem_dither(y, x);
+                const bool ok = (r < NP) & (y >= 0) & (y < aH) & (x >= 0) & (x < aW);
+                okm |= (ok ? 1u : 0u) << k;
+                at[k] = ((size_t)b * aH + min(max(y, 0), aH - 1)) * aW + min(max(x, 0), aW - 1);
+            }
+            if (a.u1) {  // wave-uniform: fiunet_forward_u8 reads the uint8 frames right here
+                unsigned char q0[NB], q1[NB];
+#pragma unroll
+                for (int k = 0; k < NB; ++k) { q0[k] = a.u1[at[k]]; q1[k] = a.u2[at[k]]; }
+#pragma unroll
+                for (int k = 0; k < NB; ++k) { v0[k] = preprocess_u8_value(q0[k]); v1[k] = preprocess_u8_value(q1[k]); }
+            } else {
+#pragma unroll
+                for (int k = 0; k < NB; ++k) { v0[k] = a.f1[at[k]]; v1[k] = a.f2[at[k]]; }
             }
 #pragma unroll
             for (int k = 0; k < NB; ++k) {
-                const int i = tid + k * 256;
-                // tail behind the hi image: dwords {1.0, 0} (lo: zeros): the operand of the bias k-slot
-                const unsigned hi = i < PH * PW * 2 ? pack_bf16x2(v[k], 0.f) & 0xffffu : ((i & 1) ? 0u : 0x3f80u);
-                const unsigned lo = pack_bf16x2(v[k] - __uint_as_float(hi << 16), 0.f) & 0xffffu;
-                if (i < NE) { ph[i] = (unsigned short)hi; pl[i] = (unsigned short)(i < PH * PW * 2 ? lo : 0u); }
+                const int r = tid + k * 256;
+                const int py = r / PW, px = r - py * PW;
+                // ordered input dither, +d on frame 1 and -d on frame 2 (stem_dither); the conv's zero
+                // padding stays exactly zero
+                const float d = a.dither * stem_dither(y0 - 2 + py, x0 - 2 + px);
+                const bool ok = (okm >> k) & 1u;
+                v0[k] = ok ? v0[k] + d : 0.f;
+                v1[k] = ok ? v1[k] - d : 0.f;
             }
+#pragma unroll
+            for (int k = 0; k < NB; ++k) {
+                const int r = tid + k * 256;
+                const int py = r / PW, px = r - py * PW;
+                const unsigned hi = pack_bf16x2_pk(v0[k], v1[k]);
+                const unsigned lo = pack_bf16x2_pk(v0[k] - __uint_as_float(hi << 16), v1[k] - __uint_as_float(hi & 0xffff0000u));
+                if (r < NP) {
+                    pd[py * PP + px] = hi;
+                    pd[py * PP + px + PW] = lo;
+                }
+            }
+            // bias operand (in the in-tile's row-pitch filler): PW dwords {1.0, 0}, then PW zero dwords (lo part)
+            if (tid < 2 * PW) reinterpret_cast<unsigned*>(smem + Tile::PATCH_TAIL_OFF)[tid] = tid < PW ? 0x00003f80u : 0u;
         }
     };
     // The plane's A operands: two 16-cout tiles, hi and lo parts, BatchNorm scale folded in on the
@@ -1097,21 +1157,23 @@ __global__ __launch_bounds__(256, conv_occupancy(BN, TH, TW)) void conv3x3_mfma_
     auto gather_plane_stem = [&](const StemW& w) __attribute__((always_inline)) {
         if constexpr (MODE == SRC_STEM) {
             // lane groups 0, 1, 2 read patch rows py, py+2, py+1 (so that the two groups served together
-            // by a ds_read2_b32, lanes 0-31, sit 2 * PW = 16 banks apart); lane group 3 (k = 24..31, only
-            // k = 24 has a weight: the BatchNorm shift) reads {1.0, 0} dwords from the tail behind the hi
-            // image / zeros behind lo, at the bank offset 16 away from lane group 2's dwords
-            const int drow = lc == 0 ? 0 : (lc == 1 ? 2 * PW : PW);
+            // by a ds_read2_b32, lanes 0-31, sit 2 * pitch = 16 banks apart); lane group 3 (k = 24..31, only
+            // k = 24 has a weight: the BatchNorm shift) reads the {1.0, 0} dwords / their zero lo part at one
+            // fixed address (a broadcast: at most one bank shared with lane group 2)
+            constexpr int TAIL_IDX = (Tile::PATCH_TAIL_OFF - Tile::PATCH_OFF) / 4;  // dword index relative to the patch
+            const int e_base = lc == 0 ? 0 : (lc == 1 ? 2 * PP : (lc == 2 ? PP : TAIL_IDX));
+            const int e_row = lc < 3 ? PP : 0, e_col = lc < 3 ? -1 : 0;  // lane group 3: the address does not move
             const unsigned* const ph32 = reinterpret_cast<const unsigned*>(patch);
-            const unsigned* const pl32 = reinterpret_cast<const unsigned*>(patch + PATCH_HALF);
-            static_assert((PH * PW) % 32 == 0 && Tile::PATCH_TAIL >= (32 + 4) * 4, "tail bank arithmetic");
+            const unsigned* const pl32 = ph32 + PW;  // the lo part of a patch row follows its hi part
             struct Frag { uint4 bh, bl; int dst; };  // dst < 0: lane beyond the in-tile; bit 30: outside the image
             // A wave's fragments are 64 in-tile pixels apart: (py, px) advance by constants with one
             // conditional wrap.  Lanes past the last pixel read a clamped row and store nothing.
             constexpr int DY = 64 / (TW + 2), DX = 64 % (TW + 2);
             int py = (wave * 16 + l15) / (TW + 2), px = wave * 16 + l15 - py * (TW + 2);
             auto fetch = [&](Frag& f) __attribute__((always_inline)) {
-                const int em = (int)__umul24(min(py, THP - 1), PW) + px + drow;  // v_mad_u32_u24, not the 64-bit mad
-                const int e = lc < 3 ? em : PH * PW + ((em + 16) & 31);
+                // lanes past the last in-tile pixel (py == THP, last fragment only) read one row beyond the
+                // patch - the parked stem weights, finite values - and store nothing
+                const int e = (int)__umul24(py, e_row) + (px & e_col) + e_base;  // v_mad_u32_u24, not the 64-bit mad
                 f.bh = make_uint4(ph32[e], ph32[e + 1], ph32[e + 2], ph32[e + 3]);
                 f.bl = make_uint4(pl32[e], pl32[e + 1], pl32[e + 2], pl32[e + 3]);
                 const bool ok = ((unsigned)(y0 - 1 + py) < (unsigned)aH) & ((unsigned)(x0 - 1 + px) < (unsigned)aW);
@@ -1139,7 +1201,15 @@ __global__ __launch_bounds__(256, conv_occupancy(BN, TH, TW)) void conv3x3_mfma_
                                       relu_pk_bf16(pack_bf16x2_pk(s4[1][0], s4[1][1])),
                                       relu_pk_bf16(pack_bf16x2_pk(s4[1][2], s4[1][3])));
                 if (zero) pk = make_uint4(0u, 0u, 0u, 0u);
-                if (f.dst >= 0) *reinterpret_cast<uint4*>(lds_in + row * 64 + ((lc ^ swz(row)) << 4)) = pk;
+                char* const o = lds_in + row * 64 + ((lc ^ swz(row)) << 4);
+#ifdef FIUNET_STEM_WRITE64  // A/B: the same bytes as two 8-B stores
+                if (f.dst >= 0) {
+                    *reinterpret_cast<uint2*>(o) = make_uint2(pk.x, pk.y);
+                    *reinterpret_cast<uint2*>(o + 8) = make_uint2(pk.z, pk.w);
+                }
+#else
+                if (f.dst >= 0) *reinterpret_cast<uint4*>(o) = pk;
+#endif
             };
             // two fragments per trip, operands of the next one in flight during the MFMAs of this one
             constexpr int NQ = (NIN + 15) / 16;

@@ -435,8 +435,11 @@ inline unsigned grid_for(size_t n) { return (unsigned)std::min<size_t>((n + 255)
 // The band [y_origin, y_origin + H) of an image of Hg rows (un-tiled: y_origin = 0, Hg = H).
 template <typename T>
 int forward_impl(fiunet_ctx* ctx, const float* f1, const float* f2, float* out, int B, int H,
-                 int W, char* ws, const Plan& p, hipStream_t s, int y_origin, int Hg)
+                 int W, char* ws, const Plan& p, hipStream_t s, int y_origin, int Hg,
+                 const uint8_t* u1 = nullptr, const uint8_t* u2 = nullptr, uint8_t* out_u8 = nullptr)
 {
+    // u1/u2 (uint8 frames) replace f1/f2 only where the stem is fused into conv 1's gather; out_u8 replaces
+    // out only where the head is fused into the last conv's epilogue (fiunet_forward_u8 decides)
     int hg[5];  // rows of the whole image at each pyramid level (floor halving, unet.py:28)
     hg[0] = Hg;
     for (int l = 1; l < 5; ++l) hg[l] = hg[l - 1] / 2;
@@ -541,6 +544,7 @@ int forward_impl(fiunet_ctx* ctx, const float* f1, const float* f2, float* out, 
         if (i == 1 && fuse_stem) {
             mode = SRC_STEM;
             a.f1 = f1; a.f2 = f2;
+            a.u1 = u1; a.u2 = u2;
             a.stem_w = ctx->stem_w_split;
             a.dither = stem_dither_amp;
         }
@@ -567,7 +571,7 @@ int forward_impl(fiunet_ctx* ctx, const float* f1, const float* f2, float* out, 
         }
         if (i == NCONV - 1 && !unfused) {  // fuse OutConv (unet.py:60) into the last epilogue
             epi = ctx->cf == 1 ? EPI_HEAD : EPI_HEAD3;
-            a.head_w = ctx->head_w; a.head_b = ctx->head_b; a.head_out = out; a.head_nc = ctx->cf;
+            a.head_w = ctx->head_w; a.head_b = ctx->head_b; a.head_out = out; a.head_out_u8 = out_u8; a.head_nc = ctx->cf;
             if (!(ctx->flags & FIUNET_OPT_KEEP_ALL)) a.dst = nullptr;
         }
         g_name_out = ev ? &ctx->layer_name[i] : nullptr;
@@ -815,11 +819,23 @@ int fiunet_forward_strip(fiunet_ctx* ctx, const float* frame1, const float* fram
     return forward_impl<float>(ctx, frame1, frame2, out, B, H, W, (char*)workspace, p, s, y_origin, H_image);
 }
 
+// fiunet_forward_u8: which of the three fp32 frame buffers (frame1, frame2, output logits) a forward of
+// this shape still needs - none where the stem reads the uint8 frames itself (fused stem: bf16 gray) and the
+// fused head writes uint8 itself (every fused-head forward).
+static void u8_buffers(const fiunet_ctx* ctx, int H, int W, int precision, bool* in_f32, bool* out_f32)
+{
+    const PlanOpts po = plan_opts(ctx, H, W, precision);
+    *in_f32 = !po.fused_stem;
+    *out_f32 = !po.fused_head;
+}
+
 size_t fiunet_workspace_bytes_u8(const fiunet_ctx* ctx, int B, int H, int W, int precision)
 {
     const size_t base = fiunet_workspace_bytes(ctx, B, H, W, precision);
     if (!base) return 0;
-    return base + 3 * align256((size_t)B * ctx->cf * H * W * 4);
+    bool in_f32, out_f32;
+    u8_buffers(ctx, H, W, precision, &in_f32, &out_f32);
+    return base + ((in_f32 ? 2 : 0) + (out_f32 ? 1 : 0)) * align256((size_t)B * ctx->cf * H * W * 4);
 }
 
 int fiunet_forward_u8(fiunet_ctx* ctx, const uint8_t* frame1, const uint8_t* frame2, uint8_t* out,
@@ -828,19 +844,38 @@ int fiunet_forward_u8(fiunet_ctx* ctx, const uint8_t* frame1, const uint8_t* fra
 {
     if (!ctx || !frame1 || !frame2 || !out || !workspace)
         return fail(FIUNET_ERR_INVALID_ARG, "NULL argument");
+    if (!ctx->loaded) return fail(FIUNET_ERR_NOT_LOADED, "fiunet_forward before fiunet_load_weights");
     const size_t base = fiunet_workspace_bytes(ctx, B, H, W, precision);
     if (!base) return fail(H < 16 || W < 16 ? FIUNET_ERR_BAD_SHAPE : FIUNET_ERR_INVALID_ARG, "bad shape");
+    bool in_f32, out_f32;
+    u8_buffers(ctx, H, W, precision, &in_f32, &out_f32);
     const size_t n = (size_t)B * ctx->cf * H * W, fb = align256(n * 4);
-    if (workspace_bytes < base + 3 * fb) return fail(FIUNET_ERR_WORKSPACE, "workspace too small");
+    if (workspace_bytes < base + ((in_f32 ? 2 : 0) + (out_f32 ? 1 : 0)) * fb)
+        return fail(FIUNET_ERR_WORKSPACE, "workspace too small");
+    if ((uintptr_t)workspace & 255) return fail(FIUNET_ERR_INVALID_ARG, "workspace not 256-B aligned");
     char* ws = (char*)workspace;
-    float* a = (float*)(ws + base);
-    float* b = (float*)(ws + base + fb);
-    float* o = (float*)(ws + base + 2 * fb);
+    char* extra = ws + base;
+    float *a = nullptr, *b = nullptr, *o = nullptr;
     int rc;
-    if ((rc = fiunet_preprocess_u8(frame1, a, n, stream))) return rc;
-    if ((rc = fiunet_preprocess_u8(frame2, b, n, stream))) return rc;
-    if ((rc = fiunet_forward(ctx, a, b, o, B, H, W, precision, workspace, base, stream))) return rc;
-    return fiunet_postprocess_u8(o, out, n, stream);
+    if (in_f32) {
+        a = (float*)extra; b = (float*)(extra + fb); extra += 2 * fb;
+        if ((rc = fiunet_preprocess_u8(frame1, a, n, stream))) return rc;
+        if ((rc = fiunet_preprocess_u8(frame2, b, n, stream))) return rc;
+    }
+    if (out_f32) o = (float*)extra;
+    Plan p;
+    if (!make_plan(B, H, W, precision, plan_opts(ctx, H, W, precision), p)) return fail(FIUNET_ERR_BAD_SHAPE, "bad shape");
+    HIP_TRY(hipSetDevice(ctx->device));
+    hipStream_t s = (hipStream_t)stream;
+    const uint8_t* u1 = in_f32 ? nullptr : frame1;
+    const uint8_t* u2 = in_f32 ? nullptr : frame2;
+    uint8_t* ou = out_f32 ? nullptr : out;
+    if (precision == FIUNET_BF16)
+        rc = forward_impl<__bf16>(ctx, a, b, o, B, H, W, ws, p, s, 0, H, u1, u2, ou);
+    else
+        rc = forward_impl<float>(ctx, a, b, o, B, H, W, ws, p, s, 0, H, u1, u2, ou);
+    if (rc) return rc;
+    return out_f32 ? fiunet_postprocess_u8(o, out, n, stream) : FIUNET_OK;
 }
 
 static inline int ssim_tiles(int H, int W, int* tiles_x)
@@ -923,8 +958,8 @@ size_t fiunet_ssim_gauss_workspace_bytes(int images, int H, int W)
 }
 
 int fiunet_ssim_gauss_f32(const float* img1, const float* img2, int images, int H, int W, int window_size,
-                          double* out_ssim, double* out_sqerr, void* workspace, size_t workspace_bytes,
-                          void* stream)
+                          const float* window_1d, double* out_ssim, double* out_sqerr, void* workspace,
+                          size_t workspace_bytes, void* stream)
 {
     if (!img1 || !img2 || !out_ssim || !workspace) return fail(FIUNET_ERR_INVALID_ARG, "NULL argument");
     if (images < 1 || H < 1 || W < 1) return fail(FIUNET_ERR_BAD_SHAPE, "bad image shape");
@@ -945,6 +980,10 @@ int fiunet_ssim_gauss_f32(const float* img1, const float* img2, int images, int 
         sum += win.g[x];
     }
     for (int x = 0; x < window_size; ++x) win.g[x] /= sum;
+    // the caller's own normalised window (torch's `gauss / gauss.sum()`: its reduction order decides the last
+    // bit of the sum, and the SSIM map's variance terms feel 1 ulp of the window's total at the 1e-7 level)
+    if (window_1d)
+        for (int x = 0; x < window_size; ++x) win.g[x] = window_1d[x];
     for (int x = window_size; x < 2 * GSSIM_MAXR + 1; ++x) win.g[x] = 0.f;
     hipStream_t s = (hipStream_t)stream;
     int tx = 0;

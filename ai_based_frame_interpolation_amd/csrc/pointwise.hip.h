@@ -312,8 +312,7 @@ __global__ __launch_bounds__(256) void preprocess_u8_kernel(const uint8_t* __res
                                                             float* __restrict__ out, size_t n)
 {
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
-        const float v = __fdiv_rn((float)in[i], 255.0f);
-        out[i] = __fsub_rn(__fmul_rn(2.0f, v), 1.0f);
+        out[i] = preprocess_u8_value(in[i]);
     }
 }
 
@@ -322,9 +321,7 @@ __global__ __launch_bounds__(256) void postprocess_u8_kernel(const float* __rest
                                                              uint8_t* __restrict__ out, size_t n)
 {
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
-        float v = __fdiv_rn(__fadd_rn(in[i], 1.0f), 2.0f);
-        v = fminf(fmaxf(v, 0.0f), 1.0f);
-        out[i] = (uint8_t)(int)__fmul_rn(v, 255.0f);
+        out[i] = postprocess_u8_value(in[i]);
     }
 }
 

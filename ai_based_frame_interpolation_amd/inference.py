@@ -32,11 +32,17 @@ from .unet import FrameInterpolationUNet
 def _read_gray(path: str) -> np.ndarray:
     """cv2.imread(path, cv2.IMREAD_GRAYSCALE) (inference.py:23): OpenCV when it is installed, else the
     readers of imageio_lite (PNG, BMP, PGM/PPM, .npy).  None when the file cannot be decoded."""
-    try:
-        import cv2  # type: ignore
-        return cv2.imread(path, cv2.IMREAD_GRAYSCALE)
-    except ImportError:
-        pass
+    img = None
+    # formats OpenCV does not know (.npy frames are what save_frames and the serving path write) never go
+    # through it; for everything else a None from cv2.imread falls through to the built-in readers
+    if not str(path).lower().endswith(".npy"):
+        try:
+            import cv2  # type: ignore
+            img = cv2.imread(path, cv2.IMREAD_GRAYSCALE)
+        except ImportError:
+            pass
+    if img is not None:
+        return img
     try:
         return imageio_lite.read_gray(path)
     except (ValueError, KeyError, struct_error, zlib_error, OSError):

@@ -57,6 +57,20 @@ def ssim_u8(pred: torch.Tensor, target: torch.Tensor) -> torch.Tensor:
     return _run("fiunet_ssim_u8", pred, target)
 
 
+_WINDOWS = {}
+
+
+def _gauss_1d(window_size: int, sigma: float = 1.5) -> torch.Tensor:
+    """SSIMLoss._gaussian (train.py:27-29): fp32 tensor of exp(-(x - ws//2)^2 / (2 sigma^2)) divided by
+    its own torch sum (host tensor; the kernel applies it separably)."""
+    if window_size not in _WINDOWS:
+        import math
+        g = torch.tensor([math.exp(-(x - window_size // 2) ** 2 / float(2 * sigma ** 2))
+                          for x in range(window_size)], dtype=torch.float32)
+        _WINDOWS[window_size] = (g / g.sum()).contiguous()
+    return _WINDOWS[window_size]
+
+
 def _gauss_planes(img1: torch.Tensor, img2: torch.Tensor, window_size: int):
     """-> (per-plane mean of the SSIM map [B, C] float64, per-plane sum of squared error [B, C] float64)"""
     if img1.shape != img2.shape or img1.dim() != 4:
@@ -77,11 +91,12 @@ def _gauss_planes(img1: torch.Tensor, img2: torch.Tensor, window_size: int):
         _native.check(1, "fiunet_ssim_gauss_workspace_bytes")
     ws = torch.empty(nbytes, dtype=torch.uint8, device=a.device)
     out = torch.empty((2, n), dtype=torch.float64, device=a.device)
+    win = _gauss_1d(int(window_size))
     with torch.cuda.device(a.device):
         s = torch.cuda.current_stream(a.device).cuda_stream
         _native.check(L.fiunet_ssim_gauss_f32(a.data_ptr(), t.data_ptr(), n, h, w, int(window_size),
-                                              out[0].data_ptr(), out[1].data_ptr(), ws.data_ptr(),
-                                              ctypes.c_size_t(nbytes), s), "fiunet_ssim_gauss_f32")
+                                              win.data_ptr(), out[0].data_ptr(), out[1].data_ptr(),
+                                              ws.data_ptr(), ctypes.c_size_t(nbytes), s), "fiunet_ssim_gauss_f32")
     return out[0].view(b, c), out[1].view(b, c)
 
 

@@ -165,9 +165,21 @@ class FrameInterpolationUNet(nn.Module):
         return super()._apply(fn, *a, **k)
 
     def _current_fingerprint(self):
-        if self._tracked is None:
-            self._tracked = [t for t in list(self.parameters()) + list(self.buffers())]
-        return tuple((t._version, t.data_ptr()) for t in self._tracked)
+        """(identity, autograd version, storage pointer) of every parameter and buffer.  Sees `p.add_()`,
+        `p.data = ...`, `p.copy_()`, replaced Parameters and `load_state_dict(assign=True)`.  Does NOT see
+        in-place edits made through `.data` / under `torch.no_grad()` on a `.data` alias
+        (`p.data.add_()`: `.data` carries its own version counter) - call `refresh_weights()` after those.
+        Inference-mode tensors have no version counter; they count as version 0 (their storage pointer
+        and identity still change when they are replaced)."""
+        tracked = list(self.parameters()) + list(self.buffers())  # re-listed every call: catches replaced tensors
+        fp = []
+        for t in tracked:
+            try:
+                ver = t._version
+            except RuntimeError:  # "Inference tensors do not track version counter"
+                ver = 0
+            fp.append((id(t), ver, t.data_ptr()))
+        return tuple(fp)
 
     # the HIP context holds raw pointers: never pickled / deep-copied with the module
     def __getstate__(self):
@@ -185,6 +197,7 @@ class FrameInterpolationUNet(nn.Module):
 
     def load_state_dict(self, *a, **k):
         self._ctx_dirty = True
+        self._tracked = None
         return super().load_state_dict(*a, **k)
 
     def refresh_weights(self):

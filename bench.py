@@ -355,6 +355,7 @@ def main():
     ap.add_argument("--video-frames", type=int, default=-1,
                     help="frames of the config-4 video leg (default 3000 = BASELINE configs[3]; 0 = skip)")
     ap.add_argument("--no-tile4k", action="store_true")
+    ap.add_argument("--no-fp32", action="store_true", help="skip the fp32 legs (A/B runs)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -440,7 +441,7 @@ def main():
         return
 
     cpu_baseline = parity = fp32 = None
-    if world == 1 and default_workload:
+    if world == 1 and default_workload and not args.no_fp32:
         fp32 = fp32_legs(dev)
     if world == 1 and not args.no_cpu_baseline:
         cpu_baseline, parity = cpu_legs(dev, args.precision)

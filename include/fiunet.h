@@ -111,10 +111,14 @@ int fiunet_forward_strip(fiunet_ctx* ctx, const float* frame1, const float* fram
                          size_t workspace_bytes, void* stream);
 
 /* Video-path variant: uint8 frames in, uint8 interpolated frame out, with the reference's
- * pre/post-processing fused on device: x/255*2-1 (model/inference.py:31-35) and
- * trunc(clamp((y+1)/2,0,1)*255) (model/inference.py:54-61).  frame1/2, out: device uint8
- * [B, frame_channels, H, W].  Needs workspace of fiunet_workspace_bytes + 3*B*C*H*W*4 bytes
- * (use fiunet_workspace_bytes_u8). */
+ * pre/post-processing on device: x/255*2-1 (model/inference.py:31-35) where the frames are read and
+ * trunc(clamp((y+1)/2,0,1)*255) (model/inference.py:54-61) where the output is written, bit for bit the
+ * values fiunet_preprocess_u8 -> fiunet_forward -> fiunet_postprocess_u8 give.  frame1/2, out: device uint8
+ * [B, frame_channels, H, W].  Where the stem conv is evaluated inside the next conv's gather (bf16, gray)
+ * it reads the uint8 frames itself, and every fused 1x1 head writes uint8 itself: one launch chain, no
+ * fp32 frame buffers; the other configurations (fp32 / RGB stem kernel, FIUNET_OPT_UNFUSED, FIUNET_OPT_KEEP_ALL)
+ * run the two elementwise kernels around the forward on up to three fp32 buffers.  Workspace:
+ * fiunet_workspace_bytes_u8 (query it after fiunet_set_options). */
 size_t fiunet_workspace_bytes_u8(const fiunet_ctx* ctx, int B, int H, int W, int precision);
 int fiunet_forward_u8(fiunet_ctx* ctx, const uint8_t* frame1, const uint8_t* frame2, uint8_t* out,
                       int B, int H, int W, int precision, void* workspace, size_t workspace_bytes,
@@ -149,12 +153,15 @@ int fiunet_ssim_u8(const uint8_t* pred, const uint8_t* target, int images, int H
  * pixels, so `ssim_map.mean()` (:54) is the mean of these and `.mean(1).mean(1).mean(1)` (:56) the mean
  * over a sample's C planes).  out_sqerr (may be NULL): device double[images], sum (img1 - img2)^2 of each
  * plane - CombinedLoss' MSE term (train.py:75-87) is their total / (images*H*W).  window_size must be odd
- * (the reference's default and only value is 11) and <= 31.  Workspace:
+ * (the reference's default and only value is 11) and <= 31.  window_1d: HOST pointer to the window_size
+ * normalised 1-D Gaussian weights the caller computed (train.py:27-29 with the caller's own torch, whose
+ * reduction order decides the last bit of `gauss.sum()`), or NULL to have them computed here (sequential
+ * fp32 sum; the mean SSIM then sits within ~1e-6 of the reference's).  Workspace:
  * fiunet_ssim_gauss_workspace_bytes(images, H, W), 256-B aligned.  Asynchronous on `stream`. */
 size_t fiunet_ssim_gauss_workspace_bytes(int images, int H, int W);
 int fiunet_ssim_gauss_f32(const float* img1, const float* img2, int images, int H, int W, int window_size,
-                          double* out_ssim, double* out_sqerr, void* workspace, size_t workspace_bytes,
-                          void* stream);
+                          const float* window_1d, double* out_ssim, double* out_sqerr, void* workspace,
+                          size_t workspace_bytes, void* stream);
 
 /* Parity-test hook: after a fiunet_forward on `workspace`, convert one intermediate activation
  * (NHWC in the compute precision) to fp32 NCHW at dst.  tap = 2*block + conv for the 18 fused

@@ -259,3 +259,65 @@ def test_optical_flow_baseline_delegates_to_opencv_with_the_reference_parameters
     assert np.array_equal(out[1, 0].numpy(), exp)
     with pytest.raises(RuntimeError, match="grayscale"):
         evaluation._optical_flow_u8(f0.repeat(1, 3, 1, 1), f1.repeat(1, 3, 1, 1))
+
+
+def test_npy_frames_bypass_opencv_and_imread_none_falls_back(tmp_path, monkeypatch):
+    """On a box WITH OpenCV (the reference lists it as a requirement): cv2.imread returns None for
+    `.npy`, the format save_frames / the serving path use, so `.npy` never goes through cv2, and a None
+    from cv2.imread falls through to the built-in readers instead of "Could not read image"."""
+    import sys
+    import types
+    from ai_based_frame_interpolation_amd import imageio_lite, inference
+    calls = []
+    fake = types.ModuleType("cv2")
+    fake.IMREAD_GRAYSCALE = 0
+    fake.imread = lambda path, flag=None: calls.append(path)  # returns None, like OpenCV on an unknown format
+    fake.resize = lambda img, size: imageio_lite.resize_linear_u8(img, size)
+    monkeypatch.setitem(sys.modules, "cv2", fake)
+    img = (np.arange(20 * 24).reshape(20, 24) % 251).astype(np.uint8)
+    npy = tmp_path / "frame.npy"
+    np.save(npy, img)
+    t = inference.preprocess_image(str(npy), target_size=None)
+    assert calls == [] and t.shape == (1, 1, 20, 24)
+    assert torch.equal(t, torch.from_numpy(2.0 * (img.astype(np.float32) / 255.0) - 1.0)[None, None])
+    pgm = tmp_path / "frame.pgm"
+    with open(pgm, "wb") as f:
+        f.write(b"P5\n24 20\n255\n" + img.tobytes())
+    t2 = inference.preprocess_image(str(pgm), target_size=None)
+    assert calls == [str(pgm)] and torch.equal(t2, t)
+    with pytest.raises(ValueError, match="Could not read image"):
+        inference.preprocess_image(str(tmp_path / "missing.png"))
+
+
+def test_weight_fingerprint_sees_replaced_and_inference_tensors(seeded_sd):
+    """The live-parameter fingerprint (unet.py): in-place edits, `.data =`, replaced Parameters and
+    load_state_dict(assign=True) change it; parameters created under inference_mode do not make it raise;
+    `.data.add_()` is the documented blind spot (own version counter) - refresh_weights() covers it."""
+    import ai_based_frame_interpolation_amd as P
+    m = P.FrameInterpolationUNet(bilinear=True)
+    m.load_state_dict(seeded_sd)
+    fp0 = m._current_fingerprint()
+    assert m._current_fingerprint() == fp0
+    p = m.unet.outc.conv.bias
+    with torch.no_grad():
+        p.add_(1.0)
+    fp1 = m._current_fingerprint()
+    assert fp1 != fp0
+    p.data = p.data.clone()
+    fp2 = m._current_fingerprint()
+    assert fp2 != fp1
+    m.unet.outc.conv.bias = torch.nn.Parameter(p.detach().clone())
+    fp3 = m._current_fingerprint()
+    assert fp3 != fp2
+    m.load_state_dict({k: v.clone() for k, v in seeded_sd.items()}, assign=True)
+    fp4 = m._current_fingerprint()
+    assert fp4 != fp3 and m._ctx_dirty
+    p = m.unet.outc.conv.bias
+    p.data.add_(1.0)                      # documented blind spot ...
+    assert m._current_fingerprint() == fp4
+    m._ctx_dirty = False
+    m.refresh_weights()                   # ... covered by the explicit call
+    assert m._ctx_dirty
+    with torch.inference_mode():
+        m2 = P.FrameInterpolationUNet(bilinear=True)
+    assert len(m2._current_fingerprint()) == len(fp0)  # no RuntimeError from `_version`
