@@ -239,6 +239,7 @@ __device__ __forceinline__ uint4 chunk_vlerp(const float* top, const float* bot,
     return chunk_pack<T>(r);
 }
 
+
 __device__ __forceinline__ uint4 ldg16(const char* p) { return *reinterpret_cast<const uint4*>(p); }
 
 // model/inference.py:31-35: image.astype(float32) / 255.0 ; 2.0 * image - 1.0   (numpy fp32 arithmetic)
@@ -939,20 +940,23 @@ __global__ __launch_bounds__(256, conv_occupancy(BN, TH, TW)) void conv3x3_mfma_
     int lr_y = 0, lr_x = 0;  // low-res origin of this tile's staging window
     char* const ytab = smem + Tile::TAB_OFF;          // [THP]   {off0, off1 (bytes into staging; < 0: zero row), hy, ly}
     char* const xtab = ytab + THP * 16;               // [TW+2]  {s0, s1 (bytes; < 0: zero column), hx, lx}
+    uint4 yrow = make_uint4(0u, 0u, 0u, 0u);         // lane l < THP: ytab[l] (CONCAT_UP)
     if constexpr (MODE == SRC_CONCAT_UP) {
         const UpCoord u = up_coord(a, y0 - 1, x0 - 1);
         lr_y = u.y0; lr_x = u.x0;
         // the mapping of in-tile row py / column px, evaluated ONCE per tile (it is the same for
         // every plane); published by the barrier that ends the prologue
-        if (tid < THP) {
-            const int y = y0 - 1 + tid;
+        {   // every wave keeps the row table in its own lanes 0 .. THP-1 as well: the column walk fetches
+            // row py's entry with v_readlane (no LDS round trip per row; the walk is latency-bound)
+            const int y = y0 - 1 + min(lane, THP - 1);
             const UpAxis uy = up_axis_y(a, min(max(y, 0), a.H - 1));
             const bool ok = uy.ok & (y >= 0) & (y < a.H);
-            *reinterpret_cast<uint4*>(ytab + tid * 16) =
-                make_uint4(ok ? (unsigned)((uy.i0 - lr_y) * (Tile::LRP * 64)) : 0x80000000u,
-                           (unsigned)((uy.i1 - lr_y) * (Tile::LRP * 64)), __float_as_uint(uy.h),
-                           __float_as_uint(uy.l));
-        } else if (tid >= 64 && tid < 64 + TW + 2) {
+            yrow = make_uint4(ok ? (unsigned)((uy.i0 - lr_y) * (Tile::LRP * 64)) : 0x80000000u,
+                              (unsigned)((uy.i1 - lr_y) * (Tile::LRP * 64)), __float_as_uint(uy.h),
+                              __float_as_uint(uy.l));
+            if (tid < THP) *reinterpret_cast<uint4*>(ytab + tid * 16) = yrow;
+        }
+        if (tid >= 64 && tid < 64 + TW + 2) {
             const int px = tid - 64, x = x0 - 1 + px;
             const UpAxis ux = up_axis_x(a, min(max(x, 0), a.W - 1));
             const bool ok = ux.ok & (x >= 0) & (x < a.W);
@@ -998,11 +1002,24 @@ __global__ __launch_bounds__(256, conv_occupancy(BN, TH, TW)) void conv3x3_mfma_
             for (int i = 0; i < NE; ++i) h0[i] = h1[i] = 0.f;
             int c0 = -1, c1 = -1;  // staging row offsets currently held in h0 / h1 (wave-uniform)
             const int rbeg = seg * UP_SEGR, rend = min(THP, rbeg + UP_SEGR);
+            // Row py's table entry comes from the wave's own lane py (v_readlane: no LDS round trip per row;
+            // up3.0 -1.5 %, up4.0 -2.3 % against the LDS read, profiles/r03_ab_lerp_variants.txt).  Tried on
+            // top of it and dropped, same file: the one new low-res row of the NEXT output row requested an
+            // iteration early (1-1.5 % slower: the walk is not bound by LDS latency), the arithmetic on
+            // float pairs (v_pk_fma_f32: null), s_setprio 3 for the walk (null).
 #pragma unroll 1
             for (int py = rbeg; py < rend; ++py) {
+#ifdef FIUNET_YTAB_LDS  // A/B: the row entry through LDS
                 const uint4 yt = *reinterpret_cast<const uint4*>(ytab + py * 16);  // same address in every lane
                 const int o0 = __builtin_amdgcn_readfirstlane((int)yt.x);
                 const int o1 = __builtin_amdgcn_readfirstlane((int)yt.y);
+#else
+                const uint4 yt = make_uint4((unsigned)__builtin_amdgcn_readlane((int)yrow.x, py),
+                                            (unsigned)__builtin_amdgcn_readlane((int)yrow.y, py),
+                                            (unsigned)__builtin_amdgcn_readlane((int)yrow.z, py),
+                                            (unsigned)__builtin_amdgcn_readlane((int)yrow.w, py));
+                const int o0 = (int)yt.x, o1 = (int)yt.y;
+#endif
                 uint4 v = make_uint4(0u, 0u, 0u, 0u);
                 if (o0 >= 0) {  // rows outside the image / the upsampled extent stay zero (conv pad, F.pad)
                     if (o0 != c0) {

@@ -130,6 +130,23 @@ def _pair_batches(n_pairs: int, batch: int):
         yield s, min(batch, n_pairs - s)
 
 
+def _forward_u8_chunk(model, a: torch.Tensor, b: torch.Tensor, batch: int, pad_ragged: bool) -> torch.Tensor:
+    """forward_u8 of one chunk of a sequence.  Below ~720p some layers of a forward have fewer workgroups
+    than the chip has CUs and cut their K loop over several (split-K, fiunet.hip); how many depends on the
+    batch, so the fp32 summation order - hence a pixel sitting on a uint8 truncation boundary - of a pair
+    may depend on how many pairs share its call.  A ragged LAST chunk of such frames is therefore run as a
+    full batch (its last pair repeated, the extra outputs dropped): every pair of a sequence is computed
+    exactly as in a full batch, and the result does not depend on the sequence length."""
+    cnt = a.shape[0]
+    if pad_ragged and cnt < batch and a.shape[-2] * a.shape[-1] < 1280 * 720:
+        rep = [1] * a.dim()
+        rep[0] = batch - cnt
+        a = torch.cat([a, a[-1:].repeat(*rep)])
+        b = torch.cat([b, b[-1:].repeat(*rep)])
+        return model.forward_u8(a, b)[:cnt]
+    return model.forward_u8(a, b)
+
+
 @torch.no_grad()
 def interpolate_sequence(model, frames_u8: torch.Tensor, batch: int = 8) -> torch.Tensor:
     """factor-2 video loop on one GPU: device uint8 frames [N,H,W] (or [N,C,H,W]) ->
@@ -141,7 +158,8 @@ def interpolate_sequence(model, frames_u8: torch.Tensor, batch: int = 8) -> torc
     out = torch.empty((2 * n - 1,) + tuple(fr.shape[1:]), dtype=torch.uint8, device=fr.device)
     out[0::2] = fr
     for s, cnt in _pair_batches(n - 1, batch):
-        out[2 * s + 1: 2 * (s + cnt): 2] = model.forward_u8(fr[s:s + cnt], fr[s + 1:s + cnt + 1])
+        out[2 * s + 1: 2 * (s + cnt): 2] = _forward_u8_chunk(model, fr[s:s + cnt], fr[s + 1:s + cnt + 1], batch,
+                                                              pad_ragged=s > 0)
     return out.squeeze(1) if squeeze else out
 
 
@@ -185,7 +203,7 @@ def interpolate_sequence_host(model, frames_u8_cpu: torch.Tensor, batch: int = 8
             upload(i + 1)
         compute.wait_event(up_done[i])
         fr = dbuf[i]
-        dmid[i] = model.forward_u8(fr[:-1], fr[1:])
+        dmid[i] = _forward_u8_chunk(model, fr[:-1], fr[1:], batch, pad_ragged=i > 0)
         comp_done[i] = torch.cuda.Event(); comp_done[i].record(compute)
         fr.record_stream(compute)
         download(i)
