@@ -226,6 +226,27 @@ def cpu_legs(dev, precision):
         out = m(fa.to(dev), fc.to(dev)).cpu()
         par[f"max_abs_{prec}_vs_cpu_ref"] = round(float((out - ref).abs().max()), 8)
     par["psnr_delta_db"] = round(abs(par[f"psnr_hip_{precision}_vs_truth_db"] - par["psnr_cpu_vs_truth_db"]), 4)
+    # ---- the same criterion over more scenes, sizes and checkpoint seeds (bounded: ~5 s of CPU) ----
+    sweep_rows, worst = [], 0.0
+    for (sh, sw), scenes, ckpts in (((256, 256), (3, 4, 5, 6, 7), (4321, 5321)), ((540, 960), (3, 5, 7), (4321,))):
+        for ck in ckpts:
+            sd_k = sd_i if ck == 4321 else O.make_interpolating_state_dict(seed=ck)
+            mk = m
+            if ck != 4321:
+                mk = P.FrameInterpolationUNet(bilinear=True)
+                mk.load_state_dict(sd_k)
+                mk = mk.to(dev).eval()
+            mk.precision = precision
+            for sc in scenes:
+                a8, t8, c8 = S.triplet(sh, sw, device="cpu", seed=sc)
+                r8 = O.postprocess_tensor(O.unet_forward(sd_k, O.preprocess_array(a8.numpy()), O.preprocess_array(c8.numpy())))
+                h8 = mk.forward_u8(a8[None, None].to(dev), c8[None, None].to(dev))[0, 0].cpu().numpy()
+                d = O.psnr_u8(t8.numpy(), h8) - O.psnr_u8(t8.numpy(), r8)
+                sweep_rows.append({"size": f"{sw}x{sh}", "scene": sc, "ckpt": ck, "delta_db": round(d, 4)})
+                worst = max(worst, abs(d))
+    par["psnr_delta_sweep"] = {"precision": precision, "cases": len(sweep_rows) + 1,
+                               "worst_abs_delta_db": round(max(worst, par["psnr_delta_db"]), 4),
+                               "bound_db": 0.05, "rows": sweep_rows}
     # ---- raw bf16 error of the bench's own random network (bounded size: 540x960) --------
     bm = make_bench_model(precision).to(dev).eval()
     sd_b = {k: v.detach().cpu() for k, v in bm.state_dict().items()}

@@ -1,6 +1,7 @@
 """Summarise rocprofv3 PMC passes of `bench.py` into profiles/pmc_summary.json + a text table.
 
-usage: python tools/pmc_summary.py gpurun_out/prof_default profiles/r02_pmc [forwards] [commit] [--no-summary-json]
+usage: python tools/pmc_summary.py gpurun_out/prof_default profiles/r03_pmc [forwards] [commit] [--no-summary-json]
+           [--workload B,H,W,bytes_per_element]   (default 8,1080,1920,2: the bench's default workload)
 Each pass directory holds one *_counter_collection.csv (one row per dispatch and counter).
 Corrections per /opt/skills/guides/MI355X_MICROARCH.md (HBM / rocprofv3): FETCH_SIZE and
 WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE counts 128-B requests as 64 B for wide coalesced
@@ -14,6 +15,9 @@ src, out = sys.argv[1], sys.argv[2]
 NFW = int(sys.argv[3]) if len(sys.argv) > 3 else 4  # forwards in the profiled bench run
 COMMIT = sys.argv[4] if len(sys.argv) > 4 and not sys.argv[4].startswith("--") else "?"
 WRITE_SUMMARY = "--no-summary-json" not in sys.argv
+WB, WH, WW, WES = 8, 1080, 1920, 2
+if "--workload" in sys.argv:
+    WB, WH, WW, WES = (int(v) for v in sys.argv[sys.argv.index("--workload") + 1].split(","))
 
 def load(pass_name):
     files = glob.glob(os.path.join(src, pass_name, "*", "*_counter_collection.csv"))
@@ -89,7 +93,9 @@ with open(out + "_table.txt", "w") as fh:
                 f"{st['lds_bank_conflict_per_active']:7.3f} {100*st['wave_wait_any_frac']:6.1f} {100*st['wave_wait_inst_frac']:6.1f}")
         print(line); fh.write(line + "\n")
     tot = sum(s["hbm_bytes"] for s in stages)
-    line = f"total HBM bytes per forward (B=8): {tot/1e9:.2f} GB; algorithmic fused-ideal: {8*2146.1e6*2/1e9:.2f} GB"
+    ideal = WB * 2146.1e6 * (WH * WW) / (1080 * 1920) * WES  # 2146.1 M elements per 1080p frame
+    line = (f"total HBM bytes per forward (B={WB} {WW}x{WH}, {WES} B/element): {tot/1e9:.2f} GB; "
+            f"algorithmic fused-ideal: {ideal/1e9:.2f} GB")
     print(line); fh.write(line + "\n")
 # bench.py reads profiles/pmc_summary.json for roofline.traffic (default workload only)
 if WRITE_SUMMARY:
