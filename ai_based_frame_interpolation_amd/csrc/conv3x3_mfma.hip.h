@@ -639,6 +639,51 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x4 (&acc)[4]
             }
         }
     }
+    if constexpr (EPI == EPI_POOL && PERM) {
+        // bf16 + fused MaxPool2d(2) (unet.py:28): a wave owns whole row pairs (fragments n and n + FR), the
+        // column partner is the neighbouring lane (l15 ^ 1).  The packed, relu'd pairs are built ONCE and
+        // used for both the full-resolution store and the pooled one (relu and the bf16 rounding are
+        // monotonic and every value is >= 0 after the relu, so the packed int16 max of the stored bits IS
+        // the pooled tensor; the epilogue's VALU instructions are paid at the partner wave's MFMA cadence).
+#pragma unroll
+        for (int n = 0; n < NF; ++n) {
+            if (((n / FR) & 1) != 0) continue;  // upper row of each pair
+            uint4 pk[2][2];
+#pragma unroll
+            for (int r = 0; r < 2; ++r) {
+                const int nn = n + r * FR;
+                const int y = y0 + wp * ROWS_W + nn / FR;
+                const int x = x0 + (nn % FR) * 16 + l15;
+                const bool ok = (y < aH) && (x < aW);
+                char* o = out_img + (size_t)(y * aW + x) * 64;
+#pragma unroll
+                for (int g = 0; g < 2; ++g) {
+                    uint4 v = make_uint4(pack_bf16x2_pk(acc[2 * g][nn][0], acc[2 * g][nn][1]),
+                                         pack_bf16x2_pk(acc[2 * g][nn][2], acc[2 * g][nn][3]),
+                                         pack_bf16x2_pk(acc[2 * g + 1][nn][0], acc[2 * g + 1][nn][1]),
+                                         pack_bf16x2_pk(acc[2 * g + 1][nn][2], acc[2 * g + 1][nn][3]));
+                    if (a.relu) v = make_uint4(relu_pk_bf16(v.x), relu_pk_bf16(v.y), relu_pk_bf16(v.z), relu_pk_bf16(v.w));
+                    pk[r][g] = v;
+                    if (ok && out_img) *reinterpret_cast<uint4*>(o + g * plane_stride) = v;
+                }
+            }
+            const int y = y0 + wp * ROWS_W + n / FR;
+            const int x = x0 + (n % FR) * 16 + l15;
+            const int py = y >> 1, px = x >> 1;
+            const bool okp = (py < pH) && (px < pW) && ((l15 & 1) == 0);
+            char* o = pool_img + (size_t)(min(py, pH - 1) * pW + min(px, pW - 1)) * 64;
+#pragma unroll
+            for (int g = 0; g < 2; ++g) {
+                const uint4 t = pk[0][g], u = pk[1][g];
+                const unsigned c0 = pk_max_i16(t.x, u.x), c1 = pk_max_i16(t.y, u.y);
+                const unsigned c2 = pk_max_i16(t.z, u.z), c3 = pk_max_i16(t.w, u.w);
+                const uint4 m = make_uint4(pk_max_i16(c0, dpp_swap_pairs(c0)), pk_max_i16(c1, dpp_swap_pairs(c1)),
+                                           pk_max_i16(c2, dpp_swap_pairs(c2)), pk_max_i16(c3, dpp_swap_pairs(c3)));
+                if (okp) *reinterpret_cast<uint4*>(o + g * pplane_stride) = m;
+            }
+        }
+        return;
+    }
 #pragma unroll
     for (int n = 0; n < NF; ++n) {
         const int y = y0 + wp * ROWS_W + n / FR;
@@ -831,20 +876,7 @@ __global__ __launch_bounds__(256, conv_occupancy(BN, TH, TW)) void conv3x3_mfma_
     // and re-read every row for every tap instead; same tap order, same sums.
     constexpr bool ROLL = sizeof(T) == 2 && FR == 2 && EPI != EPI_SPLITK;
     constexpr int NPW = (NPIECE + 3) / 4;
-    auto piece_off = [&](int j, int opq) __attribute__((always_inline)) {
-        const int row = j * 16 + (lane >> 2) + opq;
-        const int py = row / TWP, px = row - py * TWP;
-        const int y = y0 - 1 + py, x = x0 - 1 + px;
-        const bool ok = (px < TW + 2) & (py < THP) & (y >= 0) & (y < aH) & (x >= 0) & (x < aW);
-        // one image plane is < 4 GiB, so a 32-bit byte offset from the plane base is enough;
-        // ~0u marks padding (lane switched off, slot zeroed once)
-        return ok ? (unsigned)(y * aW + x) * 64u + (((lane & 3) ^ swz(row)) << 4) : ~0u;
-    };
     unsigned in_off[HOIST ? NPW : 1];
-    if (HOIST) {
-#pragma unroll
-        for (int jj = 0; jj < NPW; ++jj) in_off[jj] = piece_off(wave + 4 * jj, 0);
-    }
     const unsigned plane_bytes = (unsigned)(aH * aW) * 64u;
     // Walk over this wave's pieces: f(j, ok, off) with off = byte offset of the lane's 16 B inside a
     // plane of the source image (valid when ok).  Hoisted kernels read the stored offsets.  The others
@@ -857,17 +889,22 @@ __global__ __launch_bounds__(256, conv_occupancy(BN, TH, TW)) void conv3x3_mfma_
     static_assert(NPW <= 32, "one mask bit per piece of a wave");
     constexpr int PM_DY = 64 / TWP, PM_DX = 64 % TWP;
     const unsigned pm_dlin = (unsigned)(PM_DY * aW + PM_DX) * 64u, pm_dwrap = (unsigned)(aW - TWP) * 64u;
-    if constexpr (!HOIST && MODE != SRC_STEM) {
+    if constexpr (MODE != SRC_STEM) {
+        // one division per tile; every further piece is the previous one + 64 in-tile pixels (the hoisted
+        // kernels keep the resulting offsets, the others the first offset and two bit masks)
         const int row0 = wave * 16 + (lane >> 2);
         int py = row0 / TWP, px = row0 - py * TWP;
         int y = y0 - 1 + py, x = x0 - 1 + px;
         pm_lin0 = (unsigned)(y * aW + x) * 64u + (((lane & 3) ^ swz(row0)) << 4);
+        unsigned lin = pm_lin0;
 #pragma unroll
         for (int jj = 0; jj < NPW; ++jj) {
             const bool ok = (px < TW + 2) & ((unsigned)y < (unsigned)aH) & ((unsigned)x < (unsigned)aW);
+            if constexpr (HOIST) in_off[jj] = ok ? lin : ~0u;
             pm_valid |= (ok ? 1u : 0u) << jj;
             px += PM_DX; x += PM_DX; y += PM_DY;
-            if (px >= TWP) { px -= TWP; x -= TWP; y += 1; pm_wrap |= 1u << jj; }
+            lin += pm_dlin;
+            if (px >= TWP) { px -= TWP; x -= TWP; y += 1; pm_wrap |= 1u << jj; lin += pm_dwrap; }
         }
     }
     auto for_pieces = [&](auto&& f) __attribute__((always_inline)) {
@@ -1024,6 +1061,8 @@ __global__ __launch_bounds__(256, conv_occupancy(BN, TH, TW)) void conv3x3_mfma_
                 if (o0 >= 0) {  // rows outside the image / the upsampled extent stay zero (conv pad, F.pad)
                     if (o0 != c0) {
                         if (o0 == c1) {
+                            // (swapping the roles of h0 / h1 instead of copying - two instantiations of the
+                            // row step chosen by a wave-uniform flag - measured 4-9 % SLOWER on up3.0 / up4.0)
 #pragma unroll
                             for (int i = 0; i < NE; ++i) h0[i] = h1[i];
                         } else {
@@ -1178,25 +1217,33 @@ __global__ __launch_bounds__(256, conv_occupancy(BN, TH, TW)) void conv3x3_mfma_
             // k = 24 has a weight: the BatchNorm shift) reads the {1.0, 0} dwords / their zero lo part at one
             // fixed address (a broadcast: at most one bank shared with lane group 2)
             constexpr int TAIL_IDX = (Tile::PATCH_TAIL_OFF - Tile::PATCH_OFF) / 4;  // dword index relative to the patch
-            const int e_base = lc == 0 ? 0 : (lc == 1 ? 2 * PP : (lc == 2 ? PP : TAIL_IDX));
-            const int e_row = lc < 3 ? PP : 0, e_col = lc < 3 ? -1 : 0;  // lane group 3: the address does not move
             const unsigned* const ph32 = reinterpret_cast<const unsigned*>(patch);
             const unsigned* const pl32 = ph32 + PW;  // the lo part of a patch row follows its hi part
-            struct Frag { uint4 bh, bl; int dst; };  // dst < 0: lane beyond the in-tile; bit 30: outside the image
-            // A wave's fragments are 64 in-tile pixels apart: (py, px) advance by constants with one
-            // conditional wrap.  Lanes past the last pixel read a clamped row and store nothing.
+            struct Frag { uint4 bh, bl; int dst; };  // dst = in-tile row of the lane's pixel, >= THP*TWP: lane beyond the in-tile
+            // A wave's fragments are 64 in-tile pixels apart: the lane's patch index `e` and in-tile row `dst`
+            // advance by constants, plus a constant more when the pixel column wraps into the next row.
+            // Every VALU instruction here is paid at the partner wave's MFMA cadence (~16 cycles while the
+            // co-resident workgroup streams MFMAs on this SIMD), so the loop carries nothing it can do
+            // without: no multiplies, no coordinates besides the column, and in-tile pixels outside the
+            // image are NOT tested here - the few tiles on the image border re-zero them in a separate pass.
             constexpr int DY = 64 / (TW + 2), DX = 64 % (TW + 2);
-            int py = (wave * 16 + l15) / (TW + 2), px = wave * 16 + l15 - py * (TW + 2);
+            const int py0 = (wave * 16 + l15) / (TW + 2);
+            int px = wave * 16 + l15 - py0 * (TW + 2);
+            // lane group 3's address does not move (all its increments are zero)
+            int e = lc < 3 ? py0 * PP + px + (lc == 0 ? 0 : (lc == 1 ? 2 * PP : PP)) : TAIL_IDX;
+            const int e_step = lc < 3 ? DY * PP + DX : 0, e_wrap = lc < 3 ? PP - (TW + 2) : 0;
+            int dst = py0 * TWP + px;
             auto fetch = [&](Frag& f) __attribute__((always_inline)) {
-                // lanes past the last in-tile pixel (py == THP, last fragment only) read one row beyond the
-                // patch - the parked stem weights, finite values - and store nothing
-                const int e = (int)__umul24(py, e_row) + (px & e_col) + e_base;  // v_mad_u32_u24, not the 64-bit mad
+                // lanes past the last in-tile pixel (last fragment only) read one row beyond the patch - the
+                // parked stem weights, finite values - and store nothing
                 f.bh = make_uint4(ph32[e], ph32[e + 1], ph32[e + 2], ph32[e + 3]);
                 f.bl = make_uint4(pl32[e], pl32[e + 1], pl32[e + 2], pl32[e + 3]);
-                const bool ok = ((unsigned)(y0 - 1 + py) < (unsigned)aH) & ((unsigned)(x0 - 1 + px) < (unsigned)aW);
-                f.dst = py < THP ? ((int)__umul24(py, TWP) + px) | (ok ? 0 : 1 << 30) : -1;
-                px += DX; py += DY;
-                if (px >= TW + 2) { px -= TW + 2; py += 1; }
+                f.dst = dst;
+                px += DX;
+                const bool wrap = px >= TW + 2;
+                px -= wrap ? TW + 2 : 0;
+                e += e_step + (wrap ? e_wrap : 0);
+                dst += DY * TWP + DX + (wrap ? TWP - (TW + 2) : 0);
             };
             auto compute = [&](const Frag& f) __attribute__((always_inline)) {
                 f32x4 s4[2];
@@ -1211,22 +1258,13 @@ __global__ __launch_bounds__(256, conv_occupancy(BN, TH, TW)) void conv3x3_mfma_
                 // packed row lc*4 + j of tile h is channel lc*8 + h*4 + j of the plane (host:
                 // bf16_row_to_cout): the lane's 8 values are ONE 16-B chunk of the pixel's record - one
                 // ds_write_b128 (2-way bank conflicts) instead of two ds_write_b64 (4-way)
-                const int row = f.dst & 0xffff;
-                const bool zero = (f.dst >> 30) & 1;
-                uint4 pk = make_uint4(relu_pk_bf16(pack_bf16x2_pk(s4[0][0], s4[0][1])),
-                                      relu_pk_bf16(pack_bf16x2_pk(s4[0][2], s4[0][3])),
-                                      relu_pk_bf16(pack_bf16x2_pk(s4[1][0], s4[1][1])),
-                                      relu_pk_bf16(pack_bf16x2_pk(s4[1][2], s4[1][3])));
-                if (zero) pk = make_uint4(0u, 0u, 0u, 0u);
-                char* const o = lds_in + row * 64 + ((lc ^ swz(row)) << 4);
-#ifdef FIUNET_STEM_WRITE64  // A/B: the same bytes as two 8-B stores
-                if (f.dst >= 0) {
-                    *reinterpret_cast<uint2*>(o) = make_uint2(pk.x, pk.y);
-                    *reinterpret_cast<uint2*>(o + 8) = make_uint2(pk.z, pk.w);
-                }
-#else
-                if (f.dst >= 0) *reinterpret_cast<uint4*>(o) = pk;
-#endif
+                const int row = f.dst;
+                const uint4 pk = make_uint4(relu_pk_bf16(pack_bf16x2_pk(s4[0][0], s4[0][1])),
+                                            relu_pk_bf16(pack_bf16x2_pk(s4[0][2], s4[0][3])),
+                                            relu_pk_bf16(pack_bf16x2_pk(s4[1][0], s4[1][1])),
+                                            relu_pk_bf16(pack_bf16x2_pk(s4[1][2], s4[1][3])));
+                // address = row * 64 + ((lc ^ swz(row)) << 4), with the swizzle as one xor of bit 5
+                if (row < THP * TWP) *reinterpret_cast<uint4*>(lds_in + ((row * 64 + lc * 16) ^ ((row & 4) << 3))) = pk;
             };
             // two fragments per trip, operands of the next one in flight during the MFMAs of this one
             constexpr int NQ = (NIN + 15) / 16;
@@ -1238,6 +1276,19 @@ __global__ __launch_bounds__(256, conv_occupancy(BN, TH, TW)) void conv3x3_mfma_
                 compute(fa);
                 fetch(fa);
                 if (q + 4 < NQ) compute(fb);
+            }
+            // Tiles on the image border (6 % of them at 1080p): the in-tile pixels outside the image are
+            // the NEXT conv's zero padding, not stem outputs - overwrite them with zeros once every wave's
+            // stores are done (workgroup-uniform branch; the caller's barrier publishes the result).
+            if ((y0 == 0) | (x0 == 0) | (y0 + TH >= aH) | (x0 + TW >= aW)) {
+                __syncthreads();
+                for (int i = tid; i < THP * (TW + 2) * 4; i += 256) {
+                    const int q = i >> 2, ch = i & 3;
+                    const int qy = q / (TW + 2), qx = q - qy * (TW + 2);
+                    const bool in = ((unsigned)(y0 - 1 + qy) < (unsigned)aH) & ((unsigned)(x0 - 1 + qx) < (unsigned)aW);
+                    const int row = qy * TWP + qx;
+                    if (!in) *reinterpret_cast<uint4*>(lds_in + row * 64 + ((ch ^ swz(row)) << 4)) = make_uint4(0u, 0u, 0u, 0u);
+                }
             }
         }
     };
