@@ -21,6 +21,9 @@ if "--workload" in sys.argv:
 
 def load(pass_name):
     files = glob.glob(os.path.join(src, pass_name, "*", "*_counter_collection.csv"))
+    # gpurun MERGES a call's output into the local gpurun_out/, so a directory may also hold the file of an
+    # earlier call: only the newest one belongs to this profile
+    files = sorted(files, key=os.path.getmtime)[-1:]
     rows = []
     for f in files:
         rows += list(csv.DictReader(open(f)))
