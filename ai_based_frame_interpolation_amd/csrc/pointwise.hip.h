@@ -84,9 +84,13 @@ __global__ __launch_bounds__(256) void conv3x3_first_kernel(
                 const int xx = x + dxs[g];
                 v[g] = (xx >= 0 && xx < W) ? p[g][(xt - xt0) * 16 + dxs[g]] : 0.f;
                 if constexpr (sizeof(T) == 2) {  // the conv's zero padding stays exactly zero
-                    // (row and frame of this k-slot are re-derived from koff: no registers held for them)
+                    // (row and frame of this k-slot are re-derived from koff through an opaque copy of y, so
+                    // that hipcc does not hoist one more register per k-group out of the tile loop: the RGB
+                    // instantiation would drop to one wave per SIMD)
+                    int yo = y;
+                    asm volatile("" : "+v"(yo));
                     if (xx >= 0 && xx < W)
-                        v[g] = v[g] + ((koff[g] >> 4) >= CF ? -dither : dither) * stem_dither(y + (koff[g] & 3) - 1, xx);
+                        v[g] = v[g] + ((koff[g] >> 4) >= CF ? -dither : dither) * stem_dither(yo + (koff[g] & 3) - 1, xx);
                 }
             }
         };
