@@ -6,8 +6,10 @@ the path shards with NO collective inside the forward.  What does move between r
   (2) the uint8 interpolated frames back                   (point-to-point send/recv).
 On GPUs the process group is NCCL (= RCCL on ROCm), so each transfer is an ncclSend/ncclRecv
 over the direct xGMI link between the ingest GPU and that peer: the root's 7 links are used
-in parallel, there is no ring.  Weights are not broadcast: every rank loads the same
-checkpoint from disk.  The same code runs on gloo/CPU tensors, which is how tests/ cover it.
+in parallel, there is no ring.  Weights: every rank normally loads the same checkpoint from disk
+(no collective at all); `broadcast_model_weights` is there for ranks that do not have the file - ONE
+broadcast of the flattened state (69 MB fp32).  The same code runs on gloo/CPU
+tensors, which is how tests/ cover it.
 
 One process per GPU; rank r owns the contiguous pair range partition_pairs(n, world)[r].
 
@@ -25,6 +27,27 @@ from typing import Callable, List, Optional, Tuple
 
 import torch
 import torch.distributed as dist
+
+
+def broadcast_model_weights(model, src: int = 0, group=None) -> None:
+    """one broadcast of the checkpoint from rank `src` to every rank (ncclBroadcast on
+    GPUs, 17.27 M parameters + BatchNorm statistics = 69 MB fp32), for ranks that cannot read the file.
+    All floating-point tensors of the state dict travel as ONE flat fp32 buffer in state-dict order
+    (the int64 `num_batches_tracked` counters are not used by the forward and stay local); every rank then
+    loads the received values, which marks the module's device weights stale (re-uploaded on the next
+    forward).  Every rank must have constructed the same architecture."""
+    sd = model.state_dict()
+    keys = [k for k, v in sd.items() if v.is_floating_point()]
+    dev = next(model.parameters()).device
+    flat = torch.cat([sd[k].detach().reshape(-1).to(device=dev, dtype=torch.float32) for k in keys])
+    dist.broadcast(flat, src=src, group=group)
+    if dist.get_rank(group) != src:
+        out, o = {}, 0
+        for k in keys:
+            n = sd[k].numel()
+            out[k] = flat[o:o + n].reshape(sd[k].shape).to(sd[k].dtype)
+            o += n
+        model.load_state_dict(out, strict=False)
 
 
 def partition_pairs(n_frames: int, world: int) -> List[Tuple[int, int]]:
