@@ -171,7 +171,15 @@ __global__ __launch_bounds__(256) void ssim_finalize_kernel(const double* __rest
 // conv carries ~1e-7 of rounding that this does not reproduce, far below the 1e-5 the tests ask for).
 // The same pass also returns sum (img1 - img2)^2 per plane for CombinedLoss' MSE term (train.py:75-87).
 // Roofline: HBM (8 bytes read per pixel).
-constexpr int GSSIM_TX = 64, GSSIM_TY = 16, GSSIM_MAXR = 15;
+// Tile of 16 x 32 output pixels: 36 KiB of LDS per workgroup, four workgroups per CU.  The first version
+// (64 x 16 tiles, 82 KiB, ONE workgroup per CU) was latency-bound at one wave per SIMD: 0.69 ms for 8 x 1080p
+// frames against 0.30 ms now (-DFIUNET_GSSIM_TX / _TY sweep: 32x16 0.36, 32x32 0.35, 64x8 0.51, 16x48 0.31,
+// 16x64 0.34, 8x64 0.31, 8x32 0.33 ms).
+#ifndef FIUNET_GSSIM_TX
+#define FIUNET_GSSIM_TX 16
+#define FIUNET_GSSIM_TY 32
+#endif
+constexpr int GSSIM_TX = FIUNET_GSSIM_TX, GSSIM_TY = FIUNET_GSSIM_TY, GSSIM_MAXR = 15;
 struct GaussWindow { float g[2 * GSSIM_MAXR + 1]; };  // by value in the kernel arguments
 
 // grid = (tiles_x * tiles_y, planes); dynamic LDS: 2 fp32 input tiles + 5 fp64 row-sum planes.
