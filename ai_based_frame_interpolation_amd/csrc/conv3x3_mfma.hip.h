@@ -1033,7 +1033,9 @@ __global__ __launch_bounds__(256, conv_occupancy(BN, TH, TW)) void conv3x3_mfma_
             const bool okx = (int)xt.x >= 0;
             const char* const s0 = stg + (okx ? (int)xt.x : 0) + ch * 16;
             const char* const s1 = stg + (okx ? (int)xt.y : 0) + ch * 16;
-            const float hx = __uint_as_float(xt.z), lx = __uint_as_float(xt.w);
+            // columns outside the upsampled extent (F.pad / conv padding) get zero weights instead of a
+            // per-row select: every source value is a ReLU output (>= +0), so 0 * a + 0 * b = +0 exactly
+            const float hx = okx ? __uint_as_float(xt.z) : 0.f, lx = okx ? __uint_as_float(xt.w) : 0.f;
             float h0[NE], h1[NE];
 #pragma unroll
             for (int i = 0; i < NE; ++i) h0[i] = h1[i] = 0.f;
@@ -1082,7 +1084,6 @@ __global__ __launch_bounds__(256, conv_occupancy(BN, TH, TW)) void conv3x3_mfma_
                         c1 = o1;
                     }
                     v = chunk_vlerp<T>(h0, h1, __uint_as_float(yt.z), __uint_as_float(yt.w));
-                    if (!okx) v = make_uint4(0u, 0u, 0u, 0u);
                 }
                 const int row = py * TWP + px;
                 *reinterpret_cast<uint4*>(lds_in + row * 64 + ((ch ^ swz(row)) << 4)) = v;
