@@ -131,14 +131,15 @@ def _pair_batches(n_pairs: int, batch: int):
 
 
 def _forward_u8_chunk(model, a: torch.Tensor, b: torch.Tensor, batch: int, pad_ragged: bool) -> torch.Tensor:
-    """forward_u8 of one chunk of a sequence.  Below ~720p some layers of a forward have fewer workgroups
+    """forward_u8 of one chunk of a sequence.  Below 1080p some layers of a forward have fewer workgroups
     than the chip has CUs and cut their K loop over several (split-K, fiunet.hip); how many depends on the
-    batch, so the fp32 summation order - hence a pixel sitting on a uint8 truncation boundary - of a pair
-    may depend on how many pairs share its call.  A ragged LAST chunk of such frames is therefore run as a
+    batch (at 720p a single pair still splits its deepest level, two or more do not), so the fp32 summation
+    order - hence a pixel sitting on a uint8 truncation boundary - of a pair may depend on how many pairs
+    share its call.  A ragged LAST chunk of such frames is therefore run as a
     full batch (its last pair repeated, the extra outputs dropped): every pair of a sequence is computed
     exactly as in a full batch, and the result does not depend on the sequence length."""
     cnt = a.shape[0]
-    if pad_ragged and cnt < batch and a.shape[-2] * a.shape[-1] < 1280 * 720:
+    if pad_ragged and cnt < batch and a.shape[-2] * a.shape[-1] < 1920 * 1080:
         rep = [1] * a.dim()
         rep[0] = batch - cnt
         a = torch.cat([a, a[-1:].repeat(*rep)])

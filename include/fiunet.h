@@ -92,10 +92,11 @@ size_t fiunet_workspace_bytes(const fiunet_ctx* ctx, int B, int H, int W, int pr
  * frame1, frame2: device fp32 [B, frame_channels, H, W] contiguous (NCHW);
  * out: device fp32 [B, frame_channels, H, W]; raw logits, no activation.
  * workspace: device scratch of at least fiunet_workspace_bytes(...), 256-B aligned.
- * Reproducibility: a call is deterministic (no atomics; fixed summation order).  For frames of >= 720p the
- * result of a pair does not depend on the batch it is part of or on its position (bit for bit).  Below that,
- * layers with fewer workgroups than the chip has CUs cut their K loop over several workgroups, and how many
- * depends on B, so the fp32 summation order of a pair - hence its last bit - may differ between batch sizes
+ * Reproducibility: a call is deterministic (no atomics; fixed summation order).  For frames of >= 1080p the
+ * result of a pair does not depend on the batch it is part of or on its position (bit for bit); from 720p
+ * up that holds among batches of two or more pairs.  Below that (and for a single 720p pair), layers with
+ * fewer workgroups than the chip has CUs cut their K loop over several workgroups, and how many depends on
+ * B, so the fp32 summation order of a pair - hence its last bit - may differ between batch sizes
  * (1.8e-5 in fp32 on O(1) outputs, bf16 ulp flips; the same holds for a short band of fiunet_forward_strip
  * against the whole frame).  Callers that need a sequence's result to be independent of how it was batched
  * should pad a ragged last batch to the full size (ai_based_frame_interpolation_amd/inference.py does). */

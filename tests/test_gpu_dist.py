@@ -1,0 +1,108 @@
+"""GPU, two processes on ONE card, gloo backend on device tensors: the multi-rank code paths of
+video.interpolate_video_sharded and tiling.forward_tiled_distributed with the CUDA-side logic switched on
+(side stream, pre-allocated buffer rings, record_stream, comm/compute ordering) and the real HIP
+forward behind them.  RCCL itself needs one GPU per rank, which this build's boxes do not have: what this
+covers is everything above the transport.  Results must equal the single-process ones bit for bit
+(1080p frames: no layer is ever K-split, so a pair's bits do not depend on the batch it is in)."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _model(prec):
+    import ai_based_frame_interpolation_amd as P
+    from oracle import unet_oracle as O
+    m = P.FrameInterpolationUNet(bilinear=True, precision=prec)
+    m.load_state_dict(O.make_seeded_state_dict(1234))
+    return m.to("cuda:0").eval()
+
+
+def _video_worker(rank, world, port, prec, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import ai_based_frame_interpolation_amd as P
+        from ai_based_frame_interpolation_amd import synthetic as S, video
+        dev = torch.device("cuda:0")
+        m = _model(prec)
+        n, h, w = 14, 1080, 1920           # 13 pairs: 7 + 6, sub-batches of 3 -> 3 pipelined steps, ragged ends
+        frames = S.moving_frames(0, n, h, w, device=dev, seed=5) if rank == 0 else None
+
+        def pair_fn(a, c):
+            return m.forward_u8(a.unsqueeze(1), c.unsqueeze(1)).squeeze(1)
+
+        trace = []
+        out = video.interpolate_video_sharded(pair_fn, frames, n, (h, w), dev, batch=3, trace=trace)
+        torch.cuda.synchronize()
+        if rank == 0:
+            want = P.interpolate_sequence(m, frames, batch=3)
+            q.put(("video", prec, bool(torch.equal(out, want)), len(trace)))
+        else:
+            assert out is None
+    finally:
+        dist.destroy_process_group()
+
+
+def _tile_worker(rank, world, port, prec, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from ai_based_frame_interpolation_amd import tiling
+        dev = torch.device("cuda:0")
+        m = _model(prec)
+        shape = (1, 1, 2160, 3840)           # two bands of 1088 / 1072 rows + 112-row halo: no layer of a band is K-split
+        f1 = f2 = None
+        if rank == 0:
+            g = torch.Generator(device=dev).manual_seed(3)
+            f1 = torch.rand(shape, device=dev, generator=g) * 2 - 1
+            f2 = torch.rand(shape, device=dev, generator=g) * 2 - 1
+        out = tiling.forward_tiled_distributed(m.forward_strip, f1, f2, shape, dev)
+        torch.cuda.synchronize()
+        if rank == 0:
+            q.put(("tile", prec, bool(torch.equal(out, m(f1, f2))), 0))
+        else:
+            assert out is None
+    finally:
+        dist.destroy_process_group()
+
+
+def _run(worker, prec):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=worker, args=(r, 2, port, prec, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(300)
+        assert p.exitcode == 0
+    return q.get(timeout=5)
+
+
+@pytest.mark.parametrize("prec", ["bf16", "fp32"])
+def test_sharded_video_two_ranks_on_one_gpu(prec):
+    kind, p, equal, ntrace = _run(_video_worker, prec)
+    assert (kind, p, equal) == ("video", prec, True) and ntrace == 4   # root: 2 scatters + 2 gathers to rank 1
+
+
+def test_tiled_forward_two_ranks_on_one_gpu():
+    assert _run(_tile_worker, "bf16") == ("tile", "bf16", True, 0)
