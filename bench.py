@@ -318,7 +318,9 @@ def video_leg(model, dev, dist, rank, world, n_frames, batch, h, w):
     return {"frames_in": n_frames, "frames_out": 2 * n_frames - 1, "seconds": round(dt, 4),
             "interpolated_frames_per_s": round((n_frames - 1) / dt, 2), "ranks": seen,
             "pairs_per_rank": pairs_per_rank,
-            "backend": "rccl (torch.distributed nccl) send/recv" if dist is not None else "single process",
+            "backend": ("single process" if dist is None else
+                        "rccl (torch.distributed nccl) send/recv" if dist.get_backend() == "nccl" else
+                        f"{dist.get_backend()} (REHEARSAL on one card: timings meaningless)"),
             "sub_batch_pairs": batch, "spot_check_equal_to_single_gpu": ok,
             "note": "end to end: frames resident in rank 0's HBM -> interleaved uint8 result in rank 0's HBM"}
 
@@ -386,13 +388,22 @@ def main():
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N > 1")
     dist = None
+    # Rehearsal only (never set by the driver): FIUNET_BENCH_REHEARSE=1 runs the N-rank flow on ONE card -
+    # every rank on cuda:0, gloo instead of RCCL (which needs one GPU per rank) - to exercise the multi-rank
+    # code paths of this file on a one-GPU box; its numbers mean nothing.
+    rehearse = os.environ.get("FIUNET_BENCH_REHEARSE") == "1"
+    if rehearse:
+        local_rank = 0
     if world > 1 or "RANK" in os.environ:  # under torch.distributed.run (also with one rank)
         import torch.distributed as dist
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         with _quiet_native_stdout():
             torch.cuda.set_device(local_rank)
-            dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local_rank}"),
-                                    timeout=datetime.timedelta(seconds=600))
+            if rehearse:
+                dist.init_process_group("gloo", timeout=datetime.timedelta(seconds=600))
+            else:
+                dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local_rank}"),
+                                        timeout=datetime.timedelta(seconds=600))
             dist.barrier()  # creates the RCCL communicator (and prints its banner) here, not later
             torch.cuda.synchronize()
     torch.cuda.set_device(local_rank)
