@@ -340,7 +340,8 @@ int launch_conv_maybe_split(ConvArgs a, hipStream_t s)
         // must not depend on the batch size for frames whose batches are compared bit for bit (a
         // video's ragged last chunk, B=1 vs B=8 at 1080p): layers with >= 64 workgroups PER IMAGE
         // keep round 1's rule (split below 128 workgroups in total, which such a layer never has
-        // for B >= 2); small frames, where a single pair is K-split anyway, split below 256.
+        // for B >= 2 - a SINGLE pair with 64..127 workgroups per image, e.g. the deepest level of a 720p
+        // frame, does split); small frames, where a single pair is K-split anyway, split below 256.
         const long long thr = nblk / a.B < 64 ? 256 : 128;
         if (nblk < thr && ksplit > 1 && a.kslab && a.dst) {
             ConvArgs k = a;
