@@ -93,8 +93,13 @@ def _run(worker, prec):
     for p in procs:
         p.start()
     for p in procs:
-        p.join(300)
-        assert p.exitcode == 0
+        p.join(240)
+    hung = [p for p in procs if p.is_alive()]
+    for p in hung:          # never leave a rank behind on the card
+        p.kill()
+        p.join(10)
+    assert not hung, "a rank did not finish within 240 s"
+    assert all(p.exitcode == 0 for p in procs), [p.exitcode for p in procs]
     return q.get(timeout=5)
 
 
