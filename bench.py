@@ -152,6 +152,29 @@ def _cpu_info():
     return model, len(os.sched_getaffinity(0)), quota
 
 
+def _psnr_sweep(O, m, sd_i, dev, precision):
+    """|PSNR_hip - PSNR_cpu| against a true middle frame over scenes x sizes x checkpoint seeds."""
+    rows, worst = [], 0.0
+    for (sh, sw), scenes, ckpts in (((256, 256), (3, 4, 5, 6, 7), (4321, 5321)), ((540, 960), (3, 5, 7), (4321,))):
+        for ck in ckpts:
+            sd_k = sd_i if ck == 4321 else O.make_interpolating_state_dict(seed=ck)
+            mk = m
+            if ck != 4321:
+                mk = P.FrameInterpolationUNet(bilinear=True)
+                mk.load_state_dict(sd_k)
+                mk = mk.to(dev).eval()
+            mk.precision = precision
+            for sc in scenes:
+                a8, t8, c8 = S.triplet(sh, sw, device="cpu", seed=sc)
+                r8 = O.postprocess_tensor(O.unet_forward(sd_k, O.preprocess_array(a8.numpy()),
+                                                         O.preprocess_array(c8.numpy())))
+                h8 = mk.forward_u8(a8[None, None].to(dev), c8[None, None].to(dev))[0, 0].cpu().numpy()
+                d = O.psnr_u8(t8.numpy(), h8) - O.psnr_u8(t8.numpy(), r8)
+                rows.append({"size": f"{sw}x{sh}", "scene": sc, "ckpt": ck, "delta_db": round(d, 4)})
+                worst = max(worst, abs(d))
+    return rows, worst
+
+
 def cpu_legs(dev, precision):
     from oracle import unet_oracle as O  # checker / baseline only
 
@@ -227,23 +250,10 @@ def cpu_legs(dev, precision):
         par[f"max_abs_{prec}_vs_cpu_ref"] = round(float((out - ref).abs().max()), 8)
     par["psnr_delta_db"] = round(abs(par[f"psnr_hip_{precision}_vs_truth_db"] - par["psnr_cpu_vs_truth_db"]), 4)
     # ---- the same criterion over more scenes, sizes and checkpoint seeds (bounded: ~5 s of CPU) ----
-    sweep_rows, worst = [], 0.0
-    for (sh, sw), scenes, ckpts in (((256, 256), (3, 4, 5, 6, 7), (4321, 5321)), ((540, 960), (3, 5, 7), (4321,))):
-        for ck in ckpts:
-            sd_k = sd_i if ck == 4321 else O.make_interpolating_state_dict(seed=ck)
-            mk = m
-            if ck != 4321:
-                mk = P.FrameInterpolationUNet(bilinear=True)
-                mk.load_state_dict(sd_k)
-                mk = mk.to(dev).eval()
-            mk.precision = precision
-            for sc in scenes:
-                a8, t8, c8 = S.triplet(sh, sw, device="cpu", seed=sc)
-                r8 = O.postprocess_tensor(O.unet_forward(sd_k, O.preprocess_array(a8.numpy()), O.preprocess_array(c8.numpy())))
-                h8 = mk.forward_u8(a8[None, None].to(dev), c8[None, None].to(dev))[0, 0].cpu().numpy()
-                d = O.psnr_u8(t8.numpy(), h8) - O.psnr_u8(t8.numpy(), r8)
-                sweep_rows.append({"size": f"{sw}x{sh}", "scene": sc, "ckpt": ck, "delta_db": round(d, 4)})
-                worst = max(worst, abs(d))
+    try:
+        sweep_rows, worst = _psnr_sweep(O, m, sd_i, dev, precision)
+    except Exception as e:  # noqa: BLE001 -- the sweep is an extra: report, do not take the line down
+        sweep_rows, worst = [{"error": f"{type(e).__name__}: {e}"}], 0.0
     par["psnr_delta_sweep"] = {"precision": precision, "cases": len(sweep_rows) + 1,
                                "worst_abs_delta_db": round(max(worst, par["psnr_delta_db"]), 4),
                                "bound_db": 0.05, "rows": sweep_rows}
