@@ -221,3 +221,84 @@ def write_png(path: str, img: np.ndarray) -> None:
     with open(path, "wb") as f:
         f.write(_PNG_SIG + chunk(b"IHDR", struct.pack(">IIBBBBB", w, h, 8, ctype, 0, 0, 0)) +
                 chunk(b"IDAT", zlib.compress(raw.tobytes(), 6)) + chunk(b"IEND", b""))
+
+
+# ---- uncompressed video: YUV4MPEG2 (.y4m) ------------------------------------------------------------
+# The reference writes its result videos with imageio.mimsave (codec via ffmpeg,
+# /root/reference/model/inference.py:176-202) and has no video READER at all (main.py's `video` command
+# imports a class that does not exist).  There is no codec in this image; Y4M is the
+# uncompressed container every player / ffmpeg reads and writes (`ffmpeg -i in.mp4 in.y4m`), which makes
+# FrameInterpolator.interpolate_video work on real video files: header line
+# "YUV4MPEG2 W<w> H<h> F<num>:<den> [I<p>] [A<n>:<d>] [C<colourspace>]", then per frame "FRAME\n" + planes.
+def read_y4m(path: str):
+    """-> (y [N, H, W] uint8, chroma or None, fps (num, den), colourspace tag).  `chroma` is a pair of
+    [N, Hc, Wc] uint8 arrays (U, V) for the 4:2:0 / 4:2:2 / 4:4:4 layouts, None for mono."""
+    with open(path, "rb") as f:
+        data = f.read()
+    nl = data.index(b"\n")
+    head = data[:nl].split(b" ")
+    if head[0] != b"YUV4MPEG2":
+        raise ValueError("not a YUV4MPEG2 stream")
+    w = h = None
+    fps, cs = (30, 1), "420jpeg"
+    for tok in head[1:]:
+        if tok[:1] == b"W":
+            w = int(tok[1:])
+        elif tok[:1] == b"H":
+            h = int(tok[1:])
+        elif tok[:1] == b"F":
+            n, d = tok[1:].split(b":")
+            fps = (int(n), int(d))
+        elif tok[:1] == b"C":
+            cs = tok[1:].decode()
+    if not w or not h:
+        raise ValueError("Y4M header without W/H")
+    if cs.startswith("mono"):
+        cw = ch = 0
+    elif cs.startswith("420"):
+        cw, ch = (w + 1) // 2, (h + 1) // 2
+    elif cs.startswith("422"):
+        cw, ch = (w + 1) // 2, h
+    elif cs.startswith("444") and "alpha" not in cs:
+        cw, ch = w, h
+    else:
+        raise ValueError(f"unsupported Y4M colourspace C{cs}")
+    if any(c in cs for c in ("p10", "p12", "p14", "p16", "mono16")):
+        raise ValueError(f"unsupported Y4M bit depth C{cs}")
+    fsz = w * h + 2 * cw * ch
+    ys, us, vs = [], [], []
+    pos = nl + 1
+    while pos < len(data):
+        e = data.index(b"\n", pos)
+        if not data[pos:e].startswith(b"FRAME"):
+            raise ValueError("Y4M: FRAME marker expected")
+        pos = e + 1
+        if pos + fsz > len(data):
+            raise ValueError("Y4M: truncated frame")
+        fr = np.frombuffer(data, np.uint8, fsz, pos)
+        ys.append(fr[:w * h].reshape(h, w))
+        if cw:
+            us.append(fr[w * h:w * h + cw * ch].reshape(ch, cw))
+            vs.append(fr[w * h + cw * ch:].reshape(ch, cw))
+        pos += fsz
+    if not ys:
+        raise ValueError("Y4M: no frames")
+    chroma = (np.stack(us), np.stack(vs)) if cw else None
+    return np.stack(ys), chroma, fps, cs
+
+
+def write_y4m(path: str, y: np.ndarray, chroma=None, fps=(30, 1), colourspace: str = None) -> None:
+    """y: [N, H, W] uint8; chroma: None (-> Cmono) or (U, V) planes as read_y4m returns them."""
+    y = np.ascontiguousarray(y, dtype=np.uint8)
+    n, h, w = y.shape
+    cs = colourspace or ("mono" if chroma is None else "420jpeg")
+    if (chroma is None) != cs.startswith("mono"):
+        raise ValueError("chroma planes and colourspace tag disagree")
+    with open(path, "wb") as f:
+        f.write(f"YUV4MPEG2 W{w} H{h} F{int(fps[0])}:{int(fps[1])} Ip A1:1 C{cs}\n".encode())
+        for i in range(n):
+            f.write(b"FRAME\n")
+            f.write(y[i].tobytes())
+            if chroma is not None:
+                f.write(np.ascontiguousarray(chroma[0][i], dtype=np.uint8).tobytes())
+                f.write(np.ascontiguousarray(chroma[1][i], dtype=np.uint8).tobytes())

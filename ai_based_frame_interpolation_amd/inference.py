@@ -216,14 +216,25 @@ def interpolate_sequence_host(model, frames_u8_cpu: torch.Tensor, batch: int = 8
     return out
 
 
+def _interleave_average_u8(planes: torch.Tensor) -> torch.Tensor:
+    """[N, h, w] uint8 -> [2N-1, h, w]: the originals with the rounded average of each neighbouring pair
+    in between (chroma of an inserted frame)."""
+    n = planes.shape[0]
+    out = torch.empty((2 * n - 1,) + tuple(planes.shape[1:]), dtype=torch.uint8, device=planes.device)
+    out[0::2] = planes
+    if n > 1:
+        out[1::2] = ((planes[:-1].to(torch.int16) + planes[1:].to(torch.int16) + 1) >> 1).to(torch.uint8)
+    return out
+
+
 class FrameInterpolator:
     """What main.py:95-129 expects from `model.inference` (it is missing in the reference).
 
     interpolate_frames(img1, img2): uint8 [H,W] (gray) or [H,W,3] images -> uint8 image of the
     same shape; colour images are processed per channel with the 2->1 grayscale network unless
     the checkpoint is the 6->3 variant.
-    interpolate_video(input_path, output_path, factor=2): raw .npy frame stack in/out;
-    factor must be a power of two (recursive bisection; factor 2 is the only semantics the
+    interpolate_video(input_path, output_path, factor=2): raw .npy frame stack or uncompressed
+    YUV4MPEG2 (`.y4m`) video in/out; factor must be a power of two (recursive bisection; factor 2 is the only semantics the
     reference's flags imply, main.py:57-62)."""
 
     def __init__(self, model_path=None, device="cuda", precision=None, model=None, batch=8):
@@ -248,11 +259,40 @@ class FrameInterpolator:
         o = o[0] if self.model.frame_channels == img1.shape[2] else o[:, 0]
         return o.permute(1, 2, 0).contiguous().cpu().numpy()
 
+    def _interpolate_y4m(self, input_path, output_path, factor):
+        """Uncompressed YUV4MPEG2 in -> out (`ffmpeg -i in.mp4 in.y4m` makes one; no codec exists in this
+        image).  The network is the reference's grayscale 2->1 model, so it interpolates the LUMA plane;
+        the chroma planes of an inserted frame are the rounded average of its neighbours' (an extension:
+        the reference has no colour or video path to be faithful to).  The frame rate is multiplied by
+        `factor`.  Output: `.y4m`, or a `.npy` stack of the luma frames."""
+        if self.model.frame_channels != 1:
+            raise ValueError("Y4M video goes through the grayscale (2->1) network")
+        y, chroma, fps, cs = imageio_lite.read_y4m(input_path)
+        t = torch.from_numpy(y).to(self.device)
+        cu = cv = None
+        if chroma is not None:
+            cu, cv = (torch.from_numpy(c).to(self.device) for c in chroma)
+        f = factor
+        while f > 1:
+            t = interpolate_sequence(self.model, t, self.batch)
+            if cu is not None:
+                cu, cv = (_interleave_average_u8(c) for c in (cu, cv))
+            f //= 2
+        if str(output_path).lower().endswith(".y4m"):
+            imageio_lite.write_y4m(output_path, t.cpu().numpy(),
+                                   None if cu is None else (cu.cpu().numpy(), cv.cpu().numpy()),
+                                   (fps[0] * factor, fps[1]), cs)
+        else:
+            np.save(output_path, t.cpu().numpy())
+        return t.shape[0]
+
     def interpolate_video(self, input_path, output_path, factor=2):
         if factor < 2 or factor & (factor - 1):
             raise ValueError("factor must be a power of two (the network has no time input)")
         if not os.path.exists(input_path):
             raise FileNotFoundError(f"Video file not found: {input_path}")
+        if str(input_path).lower().endswith(".y4m"):
+            return self._interpolate_y4m(input_path, output_path, factor)
         frames = np.load(input_path)
         if frames.dtype != np.uint8 or frames.ndim not in (3, 4):
             raise ValueError("expected a uint8 .npy stack [N,H,W] or [N,H,W,3]")
