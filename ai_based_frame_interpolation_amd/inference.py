@@ -130,22 +130,38 @@ def _pair_batches(n_pairs: int, batch: int):
         yield s, min(batch, n_pairs - s)
 
 
-def _forward_u8_chunk(model, a: torch.Tensor, b: torch.Tensor, batch: int, pad_ragged: bool) -> torch.Tensor:
+def _forward_u8_chunk(model, a: torch.Tensor, b: torch.Tensor, batch: int) -> torch.Tensor:
     """forward_u8 of one chunk of a sequence.  Below 1080p some layers of a forward have fewer workgroups
     than the chip has CUs and cut their K loop over several (split-K, fiunet.hip); how many depends on the
     batch (at 720p a single pair still splits its deepest level, two or more do not), so the fp32 summation
     order - hence a pixel sitting on a uint8 truncation boundary - of a pair may depend on how many pairs
-    share its call.  A ragged LAST chunk of such frames is therefore run as a
-    full batch (its last pair repeated, the extra outputs dropped): every pair of a sequence is computed
-    exactly as in a full batch, and the result does not depend on the sequence length."""
+    share its call.  EVERY ragged chunk of such frames - the last one of a sequence, and the only one of a
+    sequence shorter than a batch - is therefore run as a full batch (its last pair repeated, the extra
+    outputs dropped): every pair of a sequence is computed exactly as in a full batch, and the result does
+    not depend on the sequence length or on how the sequence is sharded over ranks (`sequence_pair_fn`).
+    The area test is a proxy for the per-layer workgroup rule of `launch_conv_maybe_split`: from 1080p up
+    no layer ever splits, whatever the batch."""
     cnt = a.shape[0]
-    if pad_ragged and cnt < batch and a.shape[-2] * a.shape[-1] < 1920 * 1080:
+    if cnt < batch and a.shape[-2] * a.shape[-1] < 1920 * 1080:
         rep = [1] * a.dim()
         rep[0] = batch - cnt
         a = torch.cat([a, a[-1:].repeat(*rep)])
         b = torch.cat([b, b[-1:].repeat(*rep)])
         return model.forward_u8(a, b)[:cnt]
     return model.forward_u8(a, b)
+
+
+def sequence_pair_fn(model, batch: int = 8):
+    """`pair_fn` for `video.interpolate_video_sharded`: uint8 `[b, H, W]` frame stacks in, uint8 middles out,
+    through the same chunk helper as the single-process loops, so a rank's ragged sub-batches of small
+    frames are padded to `batch` exactly as `interpolate_sequence` pads its own (use the same `batch` for
+    both and the sharded result equals the single-process one bit for bit at every frame size)."""
+    @torch.no_grad()
+    def pair_fn(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
+        if a.dim() == 3:
+            return _forward_u8_chunk(model, a.unsqueeze(1), b.unsqueeze(1), batch).squeeze(1)
+        return _forward_u8_chunk(model, a, b, batch)
+    return pair_fn
 
 
 @torch.no_grad()
@@ -159,8 +175,7 @@ def interpolate_sequence(model, frames_u8: torch.Tensor, batch: int = 8) -> torc
     out = torch.empty((2 * n - 1,) + tuple(fr.shape[1:]), dtype=torch.uint8, device=fr.device)
     out[0::2] = fr
     for s, cnt in _pair_batches(n - 1, batch):
-        out[2 * s + 1: 2 * (s + cnt): 2] = _forward_u8_chunk(model, fr[s:s + cnt], fr[s + 1:s + cnt + 1], batch,
-                                                              pad_ragged=s > 0)
+        out[2 * s + 1: 2 * (s + cnt): 2] = _forward_u8_chunk(model, fr[s:s + cnt], fr[s + 1:s + cnt + 1], batch)
     return out.squeeze(1) if squeeze else out
 
 
@@ -204,7 +219,7 @@ def interpolate_sequence_host(model, frames_u8_cpu: torch.Tensor, batch: int = 8
             upload(i + 1)
         compute.wait_event(up_done[i])
         fr = dbuf[i]
-        dmid[i] = _forward_u8_chunk(model, fr[:-1], fr[1:], batch, pad_ragged=i > 0)
+        dmid[i] = _forward_u8_chunk(model, fr[:-1], fr[1:], batch)
         comp_done[i] = torch.cuda.Event(); comp_done[i].record(compute)
         fr.record_stream(compute)
         download(i)

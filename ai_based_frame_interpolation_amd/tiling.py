@@ -26,6 +26,8 @@ from typing import Callable, List, NamedTuple, Optional
 import torch
 import torch.distributed as dist
 
+from . import transport
+
 HALO = 112   # rows; >= the 109-pixel receptive-field radius, multiple of 16
 ALIGN = 16   # four 2x2 max-pools
 
@@ -77,9 +79,7 @@ def forward_tiled(strip_fn: StripFn, frame1: torch.Tensor, frame2: torch.Tensor,
 
 
 def _p2p(ops):
-    if ops:
-        for w in dist.batch_isend_irecv(ops):
-            w.wait()
+    transport.p2p(ops)
 
 
 def forward_tiled_distributed(strip_fn: StripFn, frame1: Optional[torch.Tensor],

@@ -6,8 +6,9 @@ the path shards with NO collective inside the forward.  What does move between r
   (2) the uint8 interpolated frames back                   (point-to-point send/recv).
 On GPUs the process group is NCCL (= RCCL on ROCm), so each transfer is an ncclSend/ncclRecv
 over the direct xGMI link between the ingest GPU and that peer: the root's 7 links are used
-in parallel, there is no ring.  Weights: every rank normally loads the same checkpoint from disk
-(no collective at all); `broadcast_model_weights` is there for ranks that do not have the file - ONE
+in parallel, there is no ring.  On any other backend (gloo: the tests) device tensors are staged through
+pinned host memory with explicit stream synchronisation (`transport.py`); CPU tensors go as they are.
+Weights: every rank normally loads the same checkpoint from disk (no collective at all); `broadcast_model_weights` is there for ranks that do not have the file - ONE
 broadcast of the flattened state (69 MB fp32).  The same code runs on gloo/CPU
 tensors, which is how tests/ cover it.
 
@@ -27,6 +28,8 @@ from typing import Callable, List, Optional, Tuple
 
 import torch
 import torch.distributed as dist
+
+from . import transport
 
 
 def broadcast_model_weights(model, src: int = 0, group=None) -> None:
@@ -69,9 +72,7 @@ def sub_batches(n_pairs: int, batch: int) -> List[Tuple[int, int]]:
 
 
 def _p2p(ops):
-    if ops:
-        for w in dist.batch_isend_irecv(ops):
-            w.wait()
+    transport.p2p(ops)
 
 
 def scatter_frames(frames: Optional[torch.Tensor], n_frames: int, frame_shape, device,
@@ -138,7 +139,8 @@ class _Streams:
 
     def compute_after(self, works):
         """The compute stream waits for these transfers (a wait() on an NCCL work makes the
-        CURRENT stream wait for it; on gloo it blocks the host, which is what a CPU tensor needs)."""
+        CURRENT stream wait for it; on gloo it blocks the host, which is what a CPU tensor needs, and
+        for a staged device tensor the H2D copy is then queued on this, the consuming, stream)."""
         for w in works:
             w.wait()
 
@@ -241,7 +243,7 @@ def interpolate_video_sharded(pair_fn: Callable[[torch.Tensor, torch.Tensor], to
         if not ops:
             return []
         with st.on_comm():
-            return dist.batch_isend_irecv(ops)
+            return transport.batch_isend_irecv(ops)
 
     def gather_step(j):
         """every peer's j-th middles -> root, then (comm stream) into the interleaved output."""
@@ -264,7 +266,7 @@ def interpolate_video_sharded(pair_fn: Callable[[torch.Tensor, torch.Tensor], to
             return []
         st.comm_after_compute()  # the middles of step j are queued on the compute stream
         with st.on_comm():
-            works = dist.batch_isend_irecv([op for op, _ in ops])
+            works = transport.batch_isend_irecv([op for op, _ in ops])
             if is_root:
                 for w in works:
                     w.wait()  # comm stream waits for the receives, then interleaves

@@ -302,8 +302,9 @@ def video_leg(model, dev, dist, rank, world, n_frames, batch, h, w):
 
     torch.cuda.set_device(dev)  # legs run on a worker thread: the current device is per thread
 
-    def pair_fn(a, c):  # [b,H,W] uint8 planes -> [b,H,W] middles, pre/post-processing on device
-        return model.forward_u8(a.unsqueeze(1), c.unsqueeze(1)).squeeze(1)
+    # [b,H,W] uint8 planes -> [b,H,W] middles, pre/post-processing on device; ragged sub-batches of small
+    # frames padded exactly as the single-process loop pads them
+    pair_fn = P.sequence_pair_fn(model, batch)
 
     frames = S.moving_frames(0, n_frames, h, w, device=dev, seed=11) if rank == 0 else None
     out = torch.empty((2 * n_frames - 1, h, w), dtype=torch.uint8, device=dev) if rank == 0 else None
@@ -500,7 +501,10 @@ def main():
 
     cpu_baseline = parity = fp32 = None
     if world == 1 and default_workload and not args.no_fp32:
-        fp32 = fp32_legs(dev)
+        try:
+            fp32 = fp32_legs(dev)
+        except Exception as e:  # an extra leg must never cost the headline line
+            fp32 = {"error": f"{type(e).__name__}: {e}"}
     if world == 1 and not args.no_cpu_baseline:
         cpu_baseline, parity = cpu_legs(dev, args.precision)
     print(json.dumps(headline(args, world, elapsed, rows, nfw, default_workload, video_res, tile_res,

@@ -97,7 +97,7 @@ def make_seeded_state_dict(seed: int = 1234, n_channels: int = 2, n_classes: int
 
 
 def make_interpolating_state_dict(seed: int = 4321, n_channels: int = 2, n_classes: int = 1,
-                                  perturb: float = 0.03):
+                                  perturb: float = 0.03, blend=(0.5, 0.5)):
     """A checkpoint that actually interpolates, so that PSNR against a ground-truth middle frame
     means something (a random-init network sits ~15 dB from any truth, which makes
     |PSNR_a - PSNR_b| <= 0.05 dB vacuous).  Analytic part: the stem splits each input channel c
@@ -108,7 +108,10 @@ def make_interpolating_state_dict(seed: int = 4321, n_channels: int = 2, n_class
     make_seeded_state_dict, which runs through all 18 convs and is added to the output through
     the remaining head weights, scaled so that it perturbs the result by ~`perturb` rms: every
     layer and both skip / upsampled halves of every concat contribute to the output.
-    The carried maps receive no other inputs and the random maps may read them."""
+    The carried maps receive no other inputs and the random maps may read them.
+    `blend` = (weight of frame1, weight of frame2) of the analytic part; (0.5, 0.5) is the symmetric
+    interpolator, anything else is a checkpoint that does NOT blend symmetrically (a trained network
+    need not), e.g. (0.7, 0.3) or the pure copy (1, 0)."""
     sd = make_seeded_state_dict(seed, n_channels, n_classes)
     cf = n_classes
     assert n_channels == 2 * cf, "frame-pair network: n_channels == 2 * n_classes"
@@ -137,10 +140,10 @@ def make_interpolating_state_dict(seed: int = 4321, n_channels: int = 2, n_class
     hw = sd["unet.outc.conv.weight"]
     hw *= perturb / 0.25  # the seeded head gives ~0.25 rms on the seeded features
     hw[:, :nk] = 0.0
-    for o in range(cf):  # output channel o = mean of channel o of frame1 and of frame2
-        for c in (o, cf + o):
-            hw[o, 2 * c, 0, 0] = 0.5
-            hw[o, 2 * c + 1, 0, 0] = -0.5
+    for o in range(cf):  # output channel o = blend of channel o of frame1 and of frame2
+        for c, wgt in ((o, float(blend[0])), (cf + o, float(blend[1]))):
+            hw[o, 2 * c, 0, 0] = wgt
+            hw[o, 2 * c + 1, 0, 0] = -wgt
     sd["unet.outc.conv.bias"].zero_()
     return sd
 

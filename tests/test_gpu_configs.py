@@ -212,6 +212,55 @@ def test_psnr_options_dither_and_weight_rounding(dev):
     assert torch.equal(m.forward_u8(A, C), f32)
 
 
+@pytest.mark.parametrize("blend", [(0.7, 0.3), (1.0, 0.0)])
+def test_input_dither_on_checkpoints_that_do_not_blend_symmetrically(dev, blend):
+    """The ordered input dither (+d on frame 1, -d on frame 2, |d| <= 2^-9) cancels exactly in a network that
+    outputs 0.5 (f1 + f2).  A real checkpoint need not blend symmetrically: here the analytic path is
+    0.7 f1 + 0.3 f2 and the pure copy of frame 1 (the dither does not cancel at all), and the seeded RANDOM
+    checkpoint has no carried path whatsoever.  With the dither ON (the default) the PSNR criterion must
+    still hold at the north-star bound, and the raw bf16 error against the CPU reference must not be worse
+    than with it off by more than a few percent."""
+    sd = O.make_interpolating_state_dict(seed=4321, blend=blend)
+    m = P.FrameInterpolationUNet(bilinear=True, precision="bf16")
+    m.load_state_dict(sd)
+    m = m.to(dev).eval()
+    worst = {}
+    for scene in (3, 5):
+        a, truth, c = S.triplet(256, 256, device="cpu", seed=scene)
+        A, C = a[None, None].to(dev), c[None, None].to(dev)
+        ref = O.unet_forward(sd, O.preprocess_array(a.numpy()), O.preprocess_array(c.numpy()))
+        ref_u8 = O.postprocess_tensor(ref)
+        psnr_cpu = O.psnr_u8(truth.numpy(), ref_u8)
+        for name, kw in (("dither", {}), ("no_dither", {"no_dither": True})):
+            m.set_options(**kw)
+            u8 = m.forward_u8(A, C)[0, 0].cpu().numpy()
+            raw = m(O.preprocess_array(a.numpy()).to(dev), O.preprocess_array(c.numpy()).to(dev)).cpu()
+            dp = abs(O.psnr_u8(truth.numpy(), u8) - psnr_cpu)
+            rel = ((raw - ref).norm() / ref.norm()).item()
+            w = worst.setdefault(name, [0.0, 0.0])
+            w[0], w[1] = max(w[0], dp), max(w[1], rel)
+    print(f"blend {blend}: worst |dPSNR| / rel-L2 vs CPU reference:", {k: (round(v[0], 4), round(v[1], 5)) for k, v in worst.items()})
+    assert worst["dither"][0] <= 0.05, worst
+    assert worst["dither"][1] <= 1.05 * worst["no_dither"][1] + 1e-4, worst
+
+
+def test_input_dither_on_the_random_checkpoint(model, dev, seeded_sd):
+    """Seeded random checkpoint (no interpolating path at all): dither on vs off, raw bf16 error against the
+    CPU reference - both inside the bf16 contract, on not worse than off by more than 5 %."""
+    f1, f2 = O.make_frames(31, 1, 256, 256)
+    ref = O.unet_forward(seeded_sd, f1, f2)
+    model.precision = "bf16"
+    rel = {}
+    for name, kw in (("dither", {}), ("no_dither", {"no_dither": True})):
+        model.set_options(**kw)
+        out = model(f1.to(dev), f2.to(dev)).cpu()
+        rel[name] = ((out - ref).norm() / ref.norm()).item()
+    model.set_options()
+    print("random checkpoint, bf16 rel-L2 vs CPU reference:", {k: round(v, 5) for k, v in rel.items()})
+    assert rel["dither"] <= 2e-2 and rel["no_dither"] <= 2e-2
+    assert rel["dither"] <= 1.05 * rel["no_dither"], rel
+
+
 def test_bf16_error_contract_on_bench_network(dev):
     """bench.py's own random-init network (He-scaled convs, wide BatchNorm statistics) is harder on
     bf16 than the seeded test checkpoint (its output is a small residual, |out| <= 2.3, of activations

@@ -1,9 +1,13 @@
-"""GPU, two processes on ONE card, gloo backend on device tensors: the multi-rank code paths of
-video.interpolate_video_sharded and tiling.forward_tiled_distributed with the CUDA-side logic switched on
-(side stream, pre-allocated buffer rings, record_stream, comm/compute ordering) and the real HIP
-forward behind them.  RCCL itself needs one GPU per rank, which this build's boxes do not have: what this
-covers is everything above the transport.  Results must equal the single-process ones bit for bit
-(1080p frames: no layer is ever K-split, so a pair's bits do not depend on the batch it is in)."""
+"""GPU, two processes on ONE card, gloo backend: the multi-rank CONTROL FLOW of
+video.interpolate_video_sharded and tiling.forward_tiled_distributed (partitioning, per-link issue order,
+buffer rings, which stream consumes what) with the real HIP forward behind it.  RCCL needs one GPU per
+rank, which this build's boxes do not have, so the transport here is NOT the production one: gloo cannot
+move device memory in order with a HIP stream (its send/recv hand `data_ptr()` to a host thread), so
+`transport.py` stages every device tensor through pinned host memory with an explicit stream
+synchronisation on both ends.  What is checked is that the values a rank forwards and the places they
+land are right - results equal the single-process ones bit for bit - not stream ordering of RCCL
+transfers, and not xGMI.  These are the LAST tests of the GPU tier (tests/conftest.py orders the files):
+a failure here cannot mask a parity test.  On a mismatch the workers report WHERE the results differ."""
 import os
 import socket
 
@@ -23,6 +27,21 @@ def _free_port():
     return p
 
 
+def _diff_report(got, want):
+    """Where two equally shaped tensors differ: element count, row range, largest difference."""
+    if got.shape != want.shape:
+        return f"shape {tuple(got.shape)} != {tuple(want.shape)}"
+    ne = got != want
+    n = int(ne.sum())
+    if n == 0:
+        return "equal"
+    rows = ne.reshape(-1, got.shape[-2], got.shape[-1]).any(0).any(-1).nonzero().flatten()
+    lead = ne.reshape(-1, got.shape[-2] * got.shape[-1]).any(-1).nonzero().flatten().tolist()
+    d = (got.double() - want.double()).abs().max().item()
+    return (f"{n} of {ne.numel()} elements differ; leading indices {lead[:8]}; rows {int(rows[0])}..{int(rows[-1])} "
+            f"({rows.numel()} rows); max |d| {d:.3e}")
+
+
 def _model(prec):
     import ai_based_frame_interpolation_amd as P
     from oracle import unet_oracle as O
@@ -31,7 +50,7 @@ def _model(prec):
     return m.to("cuda:0").eval()
 
 
-def _video_worker(rank, world, port, prec, q):
+def _video_worker(rank, world, port, prec, h, w, q):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
@@ -42,25 +61,22 @@ def _video_worker(rank, world, port, prec, q):
         from ai_based_frame_interpolation_amd import synthetic as S, video
         dev = torch.device("cuda:0")
         m = _model(prec)
-        n, h, w = 14, 1080, 1920           # 13 pairs: 7 + 6, sub-batches of 3 -> 3 pipelined steps, ragged ends
+        n = 14                             # 13 pairs: 7 + 6, sub-batches of 3 -> 3 pipelined steps, ragged ends
         frames = S.moving_frames(0, n, h, w, device=dev, seed=5) if rank == 0 else None
-
-        def pair_fn(a, c):
-            return m.forward_u8(a.unsqueeze(1), c.unsqueeze(1)).squeeze(1)
-
+        pair_fn = P.sequence_pair_fn(m, 3)
         trace = []
         out = video.interpolate_video_sharded(pair_fn, frames, n, (h, w), dev, batch=3, trace=trace)
         torch.cuda.synchronize()
         if rank == 0:
             want = P.interpolate_sequence(m, frames, batch=3)
-            q.put(("video", prec, bool(torch.equal(out, want)), len(trace)))
+            q.put(("video", prec, bool(torch.equal(out, want)), len(trace), _diff_report(out, want)))
         else:
             assert out is None
     finally:
         dist.destroy_process_group()
 
 
-def _tile_worker(rank, world, port, prec, q):
+def _tile_worker(rank, world, port, prec, h, w, q):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     torch.cuda.set_device(0)
@@ -69,7 +85,7 @@ def _tile_worker(rank, world, port, prec, q):
         from ai_based_frame_interpolation_amd import tiling
         dev = torch.device("cuda:0")
         m = _model(prec)
-        shape = (1, 1, 2160, 3840)           # two bands of 1088 / 1072 rows + 112-row halo: no layer of a band is K-split
+        shape = (1, 1, h, w)                 # 2160x3840: two bands of 1088 / 1072 rows + 112-row halo: no layer of a band is K-split
         f1 = f2 = None
         if rank == 0:
             g = torch.Generator(device=dev).manual_seed(3)
@@ -78,18 +94,23 @@ def _tile_worker(rank, world, port, prec, q):
         out = tiling.forward_tiled_distributed(m.forward_strip, f1, f2, shape, dev)
         torch.cuda.synchronize()
         if rank == 0:
-            q.put(("tile", prec, bool(torch.equal(out, m(f1, f2))), 0))
+            whole = m(f1, f2)
+            local = tiling.forward_tiled(m.forward_strip, f1, f2, world)   # same bands, no transport
+            torch.cuda.synchronize()
+            q.put(("tile", prec, bool(torch.equal(out, whole)), 0,
+                   f"2-rank vs un-tiled: {_diff_report(out, whole)} | single-process bands vs un-tiled: "
+                   f"{_diff_report(local, whole)}"))
         else:
             assert out is None
     finally:
         dist.destroy_process_group()
 
 
-def _run(worker, prec):
+def _run(worker, prec, h, w):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=worker, args=(r, 2, port, prec, q)) for r in range(2)]
+    procs = [ctx.Process(target=worker, args=(r, 2, port, prec, h, w, q)) for r in range(2)]
     for p in procs:
         p.start()
     for p in procs:
@@ -103,11 +124,15 @@ def _run(worker, prec):
     return q.get(timeout=5)
 
 
-@pytest.mark.parametrize("prec", ["bf16", "fp32"])
-def test_sharded_video_two_ranks_on_one_gpu(prec):
-    kind, p, equal, ntrace = _run(_video_worker, prec)
-    assert (kind, p, equal) == ("video", prec, True) and ntrace == 4   # root: 2 scatters + 2 gathers to rank 1
+@pytest.mark.parametrize("prec,h,w", [("bf16", 1080, 1920), ("fp32", 1080, 1920), ("bf16", 360, 640)])
+def test_sharded_video_two_ranks_on_one_gpu(prec, h, w):
+    """360x640: the deep layers of a forward are K-split by a rule that depends on the batch, so this case
+    holds only because every ragged sub-batch is padded to a full one on both sides (`sequence_pair_fn`)."""
+    kind, p, equal, ntrace, where = _run(_video_worker, prec, h, w)
+    assert (kind, p) == ("video", prec) and equal, where
+    assert ntrace == 4   # root: 2 scatters + 2 gathers to rank 1
 
 
 def test_tiled_forward_two_ranks_on_one_gpu():
-    assert _run(_tile_worker, "bf16") == ("tile", "bf16", True, 0)
+    kind, p, equal, _, where = _run(_tile_worker, "bf16", 2160, 3840)
+    assert (kind, p) == ("tile", "bf16") and equal, where

@@ -67,6 +67,34 @@ def test_tiled_4k_bitwise_and_vs_halo_free_cut(model, dev):
     assert torch.equal(naked[..., 112:-112, :], ref[..., 112:-112, :])    # 112 rows in: exact again
 
 
+def test_tiled_4k_four_bands_against_the_oracle(model, dev, seeded_sd):
+    """BASELINE configs[4] without any process group: the 2160x3840 pair cut into the four bands of SURVEY 8d
+    config 5 (origins 0/544/1088/1632) against the CPU ORACLE itself (not against the un-tiled HIP forward):
+    fp32 within the 1e-3 contract and 1e-4 relative everywhere, with the rows either side of every cut
+    checked on their own; bf16 within the bf16 contract.  The oracle's 4K forward takes ~20-40 s of host time."""
+    f1, f2 = O.make_frames(9, 1, 2160, 3840)
+    ref = O.unet_forward(seeded_sd, f1, f2)
+    d1, d2 = f1.to(dev), f2.to(dev)
+    scale = max(1.0, ref.abs().max().item())
+    model.precision = "fp32"
+    model.set_options()
+    t32 = tiling.forward_tiled(model.forward_strip, d1, d2, 4).cpu()
+    assert t32.shape == ref.shape
+    d = (t32 - ref).abs()
+    assert d.max().item() <= 1e-3 and d.max().item() <= 1e-4 * scale, d.max().item()
+    for cut in (544, 1088, 1632):     # the seams: last rows of one band's core, first rows of the next one's
+        assert d[..., cut - 8:cut + 8, :].max().item() <= 1e-4 * scale, (cut, d[..., cut - 8:cut + 8, :].max().item())
+    model.precision = "bf16"
+    model.set_options()
+    t16 = tiling.forward_tiled(model.forward_strip, d1, d2, 4).cpu()
+    rel = ((t16 - ref).norm() / ref.norm()).item()
+    assert rel <= 2e-2, rel
+    assert (t16 - ref).abs().max().item() <= 0.04 * (ref.max() - ref.min()).item()
+    # strided sample of the kept rows: what a 4-GPU run would gather (every 7th row, every 5th column)
+    sm = (t16[..., ::7, ::5] - ref[..., ::7, ::5]).norm() / ref[..., ::7, ::5].norm()
+    assert sm.item() <= 2e-2, sm.item()
+
+
 def test_strip_uses_global_upsample_coordinates(model, dev):
     """A band evaluated with its own (local) align_corners mapping differs from the whole image's;
     forward_strip with the true origin must not.  Guards against dropping the origin."""
