@@ -1,5 +1,6 @@
 """A/B several builds of libfiunet_hip.so on ONE box: interleaved rounds, separate processes.
-usage: python tools/ab_bench.py name=path.so ... [--rounds 3] [--steps 10]"""
+usage: python tools/ab_bench.py name=path.so[,ENV=VALUE...] ... [--rounds 3] [--steps 10] [-- extra bench args]
+(`default` as the path = the in-tree library; ENV=VALUE pairs are set for that variant only)"""
 import json, os, subprocess, sys, statistics
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 args = [a for a in sys.argv[1:] if "=" in a and not a.startswith("--")]
@@ -12,6 +13,10 @@ stages = {}
 for r in range(rounds):
     for n, p in libs:
         env = dict(os.environ)
+        p, *kv = p.split(",")
+        for item in kv:
+            k, v = item.split("=", 1)
+            env[k] = v
         if p != "default":
             env["FIUNET_LIB"] = os.path.join(ROOT, p)
         out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", steps,
