@@ -406,6 +406,7 @@ def main():
                     help="frames of the config-4 video leg (default 3000 = BASELINE configs[3]; 0 = skip)")
     ap.add_argument("--no-tile4k", action="store_true")
     ap.add_argument("--no-fp32", action="store_true", help="skip the fp32 legs (A/B runs)")
+    ap.add_argument("--no-power", action="store_true", help="skip the rocm-smi power / clock sample")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -464,10 +465,16 @@ def main():
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+    default_workload = (b, h, w, args.precision, args.unfused) == (8, 1080, 1920, "bf16", False)
+    power = None
+    if world == 1 and default_workload and not args.no_power:
+        try:
+            power = power_leg(model, f1, f2, dev)
+        except Exception as e:  # an extra leg must never cost the headline line
+            power = {"error": f"{type(e).__name__}: {e}"}
     del f1, f2
 
     # ---- config 4 / config 5 legs (every rank takes part; bounded, failures are reported) ----
-    default_workload = (b, h, w, args.precision, args.unfused) == (8, 1080, 1920, "bf16", False)
     n_video = args.video_frames if args.video_frames >= 0 else (3000 if default_workload else 0)
     video_res = tile_res = None
     if n_video >= 2:
@@ -508,9 +515,67 @@ def main():
     if world == 1 and not args.no_cpu_baseline:
         cpu_baseline, parity = cpu_legs(dev, args.precision)
     print(json.dumps(headline(args, world, elapsed, rows, nfw, default_workload, video_res, tile_res,
-                              cpu_baseline, parity, fp32)))
+                              cpu_baseline, parity, fp32, power)))
     if dist is not None:
         dist.destroy_process_group()
+
+
+def power_leg(model, f1, f2, dev, seconds=4.0):
+    """Socket power and shader clock while the forward runs back to back (rocm-smi on a thread, outside the
+    timed region): is the workload at the package power cap?  Round 4 measured 1389-1393 W of 1400 W at an
+    sclk of ~1.96 GHz (profiles/r04_power_sample.txt): the forward is POWER-bound, and the MFMA peak that
+    applies is 2500 TFLOP/s x sclk / 2.4 GHz."""
+    import re
+    import subprocess
+
+    def num(v):
+        m = re.search(r"[-+]?\d+(\.\d+)?", str(v))
+        return float(m.group(0)) if m else None
+
+    def smi(*flags):
+        out = subprocess.run(["rocm-smi", "-d", str(dev.index or 0), *flags, "--json"], capture_output=True,
+                             text=True, timeout=10).stdout
+        return next(iter(json.loads(out).values()))
+
+    cap = None
+    try:
+        cap = num(next(iter(smi("--showmaxpower").values())))
+    except Exception:
+        pass
+    samples, stop = [], threading.Event()
+
+    def sampler():
+        while not stop.is_set():
+            try:
+                c = smi("--showpower", "--showclocks")
+                pw = [num(v) for k, v in c.items() if "power" in k.lower()]
+                ck = [num(v) for k, v in c.items() if k.lower().startswith("sclk clock speed")]
+                if pw and ck:
+                    samples.append((pw[0], ck[0]))
+            except Exception:
+                return
+
+    th = threading.Thread(target=sampler, daemon=True)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    model(f1, f2)
+    e1.record()
+    torch.cuda.synchronize()
+    n = max(8, int(seconds * 1e3 / max(e0.elapsed_time(e1), 1e-3)))
+    th.start()
+    for _ in range(n):      # queued back to back, one synchronisation at the end
+        model(f1, f2)
+    torch.cuda.synchronize()
+    stop.set()
+    th.join(12)
+    if not samples:
+        return {"error": "rocm-smi gave no samples"}
+    pw = sorted(s[0] for s in samples)
+    ck = sorted(s[1] for s in samples)
+    sclk = statistics.median(ck)
+    return {"socket_w_median": statistics.median(pw), "socket_w_max": pw[-1], "cap_w": cap, "sclk_mhz_median": sclk,
+            "samples": len(samples), "mfma_peak_at_sclk_tflops": round(2500.0 * sclk / 2400.0, 1),
+            "note": "rocm-smi while the forward runs back to back, outside the timed region"}
 
 
 def dominant_kernel(rows, precision):
@@ -568,7 +633,7 @@ def fp32_legs(dev):
 
 
 def headline(args, world, elapsed, rows, nfw, default_workload, video_res, tile_res, cpu_baseline, parity,
-             fp32=None):
+             fp32=None, power=None):
     b, h, w = args.batch, args.height, args.width
     fps = world * b * args.steps / elapsed
     ms_step = elapsed / args.steps * 1e3
@@ -578,12 +643,13 @@ def headline(args, world, elapsed, rows, nfw, default_workload, video_res, tile_
     # ---- roofline of the dominant kernel (grouped by kernel instantiation) ------------------
     dom_name, dom, achieved = dominant_kernel(rows, args.precision)
     peak = PEAK_TFLOPS[args.precision]
-    traffic = traffic_source = None
+    traffic = traffic_source = rocprof_avg = None
     pmc = os.path.join(ROOT, "profiles", "pmc_summary.json")
     if os.path.exists(pmc) and default_workload:  # the committed PMC pass is of this workload only
         try:
             js = json.load(open(pmc))
             traffic = js.get(dom_name, {}).get("hbm_bytes_per_launch")
+            rocprof_avg = js.get(dom_name, {}).get("rocprof_avg_launch_ms")
             meta = js.get("_meta", {})
             traffic_source = ("profiles/pmc_summary.json: separate rocprofv3 --pmc passes (FETCH_SIZE x2 "
                               "corrected + WRITE_SIZE, tools/profile_all.sh) of this command at commit "
@@ -596,6 +662,9 @@ def headline(args, world, elapsed, rows, nfw, default_workload, video_res, tile_
         "frac": round(achieved / peak, 4), "traffic": traffic, "traffic_source": traffic_source,
         "kernel": dom_name, "launches_per_step": dom["launches"],
         "avg_launch_ms": round(dom["ms"] / dom["launches"], 4),
+        # the same kernel's average in the committed `rocprofv3 --kernel-trace --stats` pass (profiles/, same source
+        # and commit as `traffic`): NOT measured by this run, quoted so that the two can be compared
+        "rocprof_avg_launch_ms_committed_profile": rocprof_avg,
         "algorithmic_flops_per_launch": dom["flops"] / dom["launches"],
         "events_forwards": nfw,
         "whole_forward": {
@@ -625,6 +694,12 @@ def headline(args, world, elapsed, rows, nfw, default_workload, video_res, tile_
         result["parity"] = parity
     if fp32 is not None:
         result["fp32"] = fp32
+    if power is not None:
+        result["power"] = power
+        if power.get("mfma_peak_at_sclk_tflops"):
+            pk = power["mfma_peak_at_sclk_tflops"]
+            roofline["frac_of_peak_at_sustained_clock"] = round(achieved / pk, 4)
+            roofline["whole_forward"]["mfma_frac_at_sustained_clock"] = round(roofline["whole_forward"]["tflops"] / pk, 4)
     if video_res is not None:
         result["video_sharded"] = video_res
     if tile_res is not None:

@@ -20,7 +20,7 @@ for r in range(rounds):
         if p != "default":
             env["FIUNET_LIB"] = os.path.join(ROOT, p)
         out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", steps,
-                              "--no-cpu-baseline"] + extra, env=env, capture_output=True, text=True)
+                              "--no-cpu-baseline", "--no-power"] + extra, env=env, capture_output=True, text=True)
         line = [l for l in out.stdout.splitlines() if l.startswith("{")]
         if not line:
             print(n, "FAILED", out.stderr[-400:]); continue

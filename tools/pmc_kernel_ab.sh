@@ -9,7 +9,7 @@ PAT=$1; shift
 O=$R/gpurun_out/pmc_ab
 rm -rf "$O"; mkdir -p "$O"
 cd /tmp && export TMPDIR=/tmp
-B="python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --video-frames 0 --no-fp32"
+B="python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --video-frames 0 --no-fp32 --no-power"
 for spec in "$@"; do
   name=${spec%%=*}; lib=${spec#*=}
   if [ "$lib" != default ]; then export FIUNET_LIB=$R/$lib; else unset FIUNET_LIB; fi
