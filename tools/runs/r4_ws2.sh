@@ -1,0 +1,4 @@
+cd $GRAFT_REPO_ROOT && mkdir -p gpurun_out/r4
+O=gpurun_out/r4
+timeout -k 10 500 python tools/ab_bench.py base=abl/lib_ws.so ws=abl/lib_ws.so,FIUNET_WS=1 nolerp=abl/lib_ws_nolerp.so,FIUNET_WS=1 nomfma=abl/lib_ws_nomfma.so,FIUNET_WS=1 --rounds 2 --steps 10 -- --video-frames 0 --no-fp32 > $O/ab_ws_diag.txt 2>&1
+tail -22 $O/ab_ws_diag.txt
