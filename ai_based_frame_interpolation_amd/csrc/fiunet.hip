@@ -473,6 +473,7 @@ int forward_impl(fiunet_ctx* ctx, const float* f1, const float* f2, float* out, 
     // an 8-bit input step peak to peak
     const float stem_dither_amp = (bf16 && !(ctx->flags & FIUNET_OPT_NO_DITHER)) ? 0.00390625f : 0.f;
     // conv 0: fp32 stem (unet.py:72, first conv of inc)
+    bool stem_split_rgb = false;
     if (run_stem) {
         const ConvWeights& cw = ctx->conv[0];
         const long long nruns = (long long)B * H * (((W + 15) / 16 + 7) / 8);  // 8-tile row runs
@@ -480,7 +481,17 @@ int forward_impl(fiunet_ctx* ctx, const float* f1, const float* f2, float* out, 
         if (ctx->cf == 1)
             hipLaunchKernelGGL((conv3x3_first_kernel<T, 1>), grid, dim3(256), 0, s, f1, f2,
                                (const float*)cw.w_f32, cw.scale, cw.shift, act(0), B, H, W, stem_dither_amp);
-        else
+        else if (bf16) {
+            // RGB bf16: split-bf16 MFMA stem (pointwise.hip.h), also on the ablation path (all 18 stage outputs of
+            // the RGB bf16 network stay bit-identical fused vs unfused); the fp32 network keeps the exact kernel
+            if constexpr (sizeof(T) == 2) {
+                const long long ntiles = (long long)B * ((H + 15) / 16) * ((W + 31) / 32);
+                dim3 g2((unsigned)std::min<long long>(ntiles, 256 * 4));
+                hipLaunchKernelGGL(stem_rgb_split_kernel, g2, dim3(256), 0, s, f1, f2, (const float*)cw.w_f32, cw.scale,
+                                   cw.shift, (__bf16*)act(0), B, H, W, stem_dither_amp);
+                stem_split_rgb = true;
+            }
+        } else
             hipLaunchKernelGGL((conv3x3_first_kernel<T, 3>), grid, dim3(256), 0, s, f1, f2,
                                (const float*)cw.w_f32, cw.scale, cw.shift, act(0), B, H, W, stem_dither_amp);
         HIP_TRY(hipGetLastError());
@@ -488,7 +499,8 @@ int forward_impl(fiunet_ctx* ctx, const float* f1, const float* f2, float* out, 
     if (ev) {
         const ConvWeights& cw = ctx->conv[0];
         HIP_TRY(hipEventRecord(ev[1], s));
-        ctx->layer_name[0] = run_stem ? std::string("conv3x3_first_kernel<") + (bf16 ? "bf16" : "f32") +
+        ctx->layer_name[0] = stem_split_rgb ? std::string("stem_rgb_split_kernel")
+                             : run_stem ? std::string("conv3x3_first_kernel<") + (bf16 ? "bf16" : "f32") +
                                             "," + std::to_string(ctx->cf) + ">"
                                       : std::string("(stem fused into next stage)");
         ctx->layer_flops[0] = run_stem ? 2.0 * B * H * W * 9.0 * cw.cin * cw.cout : 0.0;

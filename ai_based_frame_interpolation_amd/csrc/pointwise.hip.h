@@ -129,6 +129,131 @@ __global__ __launch_bounds__(256) void conv3x3_first_kernel(
     }
 }
 
+// The RGB (6 -> 64) stem of the bf16 network on the bf16 matrix cores with hi + lo split operands (round 4).
+// conv3x3_first_kernel<bf16, 3> above evaluates it on the exact-fp32 MFMA: K = 54 -> 56 fp32 MFMAs of 32 cycles per
+// 16 pixels x 64 couts, with one global load per lane and k-group in front of them - 2.97 ms per B=8 1080p forward,
+// 7x the time its 2.1 GB of output take to write, and the longest stage of the RGB network.  Here the raw patch of
+// both frames is staged once per 16x32 tile in LDS as bf16 pairs {frame1, frame2} per colour channel, hi and lo part
+// (x = xh + xl, |xl| <= 2^-9 |x|), the weights (BatchNorm scale folded in, shift riding in a bias k-slot whose data
+// operand is 1.0) are split the same way and kept in registers, and a 16-pixel fragment is
+//     acc += wh*xh + wh*xl + wl*xh        (fp32 accumulate; the dropped wl*xl term is 2^-16 relative)
+// over three 32-slot k-chunks: k-group g = chunk*4 + lane group covers (dy, colour c) = (g / 3, g % 3) for g < 9 with
+// its 8 slots = 4 columns x 2 frames of patch row r + dy (the 4th column has zero weights), g = 9 is the bias, 10-11
+// are empty - 9 bf16 MFMAs of 16 cycles per cout tile instead of 14 fp32 ones of 32.  Same scheme, and the same
+// ~2^-16 relative accuracy before the bf16 rounding of the output, as the fused gray stem (conv3x3_mfma.hip.h,
+// SRC_STEM).  /root/reference/model/unet.py:72 with n_channels = 6 (unet.py:66); channel order of torch.cat([f1, f2]).
+__global__ __launch_bounds__(256) void stem_rgb_split_kernel(
+    const float* __restrict__ f1, const float* __restrict__ f2, const float* __restrict__ w,  // w: [9 taps][6][64] fp32
+    const float* __restrict__ scale, const float* __restrict__ shift, __bf16* __restrict__ dst, int B, int H, int W,
+    float dither)
+{
+    constexpr int CF = 3, TH = 16, TW = 32, PH = TH + 2, PW = TW + 4;
+    constexpr int IMG = PH * PW;                 // dwords of one (colour, hi | lo) patch image
+    constexpr int BIAS_OFF = 6 * IMG;            // 8 dwords {1.0, 0}, 0, 0, ... (hi operand of the bias k-group)
+    constexpr int ZERO_OFF = BIAS_OFF + 8;       // 8 zero dwords (its lo operand; both operands of the empty groups)
+    __shared__ __attribute__((aligned(16))) unsigned pd[ZERO_OFF + 8];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l15 = lane & 15, lc = lane >> 4;
+
+    // ---- A operands: this lane's row of every cout tile (packed row lc'*4 + j of tile ct <-> cout lc'*16 + ct*4 + j,
+    //      so that a lane ends up with 16 consecutive couts), 8 k-slots of its lane group, for the three chunks
+    uint4 ah[3][4], al[3][4];
+    unsigned off_h[3], off_l[3], fmul[3];
+#pragma unroll
+    for (int ch = 0; ch < 3; ++ch) {
+        const int g = ch * 4 + lc, dy = g / 3, c = g - dy * 3;
+        off_h[ch] = g < 9 ? (unsigned)((c * 2) * IMG + dy * PW) : (g == 9 ? BIAS_OFF : ZERO_OFF);
+        off_l[ch] = g < 9 ? (unsigned)((c * 2 + 1) * IMG + dy * PW) : ZERO_OFF;
+        fmul[ch] = g < 9 ? 1u : 0u;
+#pragma unroll
+        for (int ct = 0; ct < 4; ++ct) {
+            const int cout = (l15 >> 2) * 16 + ct * 4 + (l15 & 3);
+            const float sc = scale[cout];
+            unsigned h[4], l[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {        // slots 2i (frame 1), 2i + 1 (frame 2) of column dx = i
+                float v0 = 0.f, v1 = 0.f;
+                if (g < 9 && i < 3) {
+                    const int tap = dy * 3 + i;
+                    v0 = w[((tap * 2 * CF) + c) * 64 + cout] * sc;
+                    v1 = w[((tap * 2 * CF) + CF + c) * 64 + cout] * sc;
+                } else if (g == 9 && i == 0) {
+                    v0 = shift[cout];
+                }
+                h[i] = pack_bf16x2_pk(v0, v1);
+                l[i] = pack_bf16x2_pk(v0 - __uint_as_float(h[i] << 16), v1 - __uint_as_float(h[i] & 0xffff0000u));
+            }
+            ah[ch][ct] = make_uint4(h[0], h[1], h[2], h[3]);
+            al[ch][ct] = make_uint4(l[0], l[1], l[2], l[3]);
+        }
+    }
+    if (tid < 16) pd[BIAS_OFF + tid] = tid == 0 ? 0x00003f80u : 0u;
+
+    const int tilesX = (W + TW - 1) / TW, tilesY = (H + TH - 1) / TH;
+    const long long ntiles = (long long)B * tilesX * tilesY;
+    const size_t plane = (size_t)H * W;
+    for (long long t = blockIdx.x; t < ntiles; t += gridDim.x) {
+        const int tx = (int)(t % tilesX);
+        const long long q = t / tilesX;
+        const int ty = (int)(q % tilesY), b = (int)(q / tilesY);
+        const int y0 = ty * TH, x0 = tx * TW;
+        __syncthreads();   // the previous tile's fragment reads are done (and the bias / zero rows are written)
+        // ---- patch: one thread per patch pixel and pass; clamped unconditional loads, zero outside the image
+        for (int i = tid; i < IMG; i += 256) {
+            const int py = i / PW, px = i - py * PW;
+            const int y = y0 - 1 + py, x = x0 - 1 + px;
+            const bool ok = (y >= 0) & (y < H) & (x >= 0) & (x < W);
+            const size_t at = (size_t)min(max(y, 0), H - 1) * W + min(max(x, 0), W - 1);
+            const float d = dither * stem_dither(y, x);
+#pragma unroll
+            for (int c = 0; c < CF; ++c) {
+                float v0 = f1[((size_t)b * CF + c) * plane + at], v1 = f2[((size_t)b * CF + c) * plane + at];
+                v0 = ok ? v0 + d : 0.f;   // +d on frame 1, -d on frame 2; the conv's zero padding stays exactly zero
+                v1 = ok ? v1 - d : 0.f;
+                const unsigned hi = pack_bf16x2_pk(v0, v1);
+                pd[(c * 2) * IMG + i] = hi;
+                pd[(c * 2 + 1) * IMG + i] = pack_bf16x2_pk(v0 - __uint_as_float(hi << 16), v1 - __uint_as_float(hi & 0xffff0000u));
+            }
+        }
+        __syncthreads();
+        // ---- fragments: wave = 4 tile rows x 2 column halves
+#pragma unroll 2
+        for (int f = 0; f < 8; ++f) {
+            const int r = wave * 4 + (f >> 1), xc = (f & 1) * 16 + l15;
+            const int y = y0 + r, x = x0 + xc;
+            f32x4 acc[4];
+#pragma unroll
+            for (int ct = 0; ct < 4; ++ct) acc[ct] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int ch = 0; ch < 3; ++ch) {
+                const unsigned o = fmul[ch] * (unsigned)(r * PW + xc);
+                const unsigned* ph = pd + off_h[ch] + o;
+                const unsigned* pl = pd + off_l[ch] + o;
+                const uint4 bh = make_uint4(ph[0], ph[1], ph[2], ph[3]);
+                const uint4 bl = make_uint4(pl[0], pl[1], pl[2], pl[3]);
+#pragma unroll
+                for (int ct = 0; ct < 4; ++ct) mma_chunk<__bf16>(acc[ct], al[ch][ct], bh);
+#pragma unroll
+                for (int ct = 0; ct < 4; ++ct) mma_chunk<__bf16>(acc[ct], ah[ch][ct], bl);
+#pragma unroll
+                for (int ct = 0; ct < 4; ++ct) mma_chunk<__bf16>(acc[ct], ah[ch][ct], bh);
+            }
+            if (y < H && x < W) {
+                // couts lc*16 .. lc*16+15 of this pixel: half of a 64-B plane record
+                char* op = (char*)dst + (size_t)b * H * W * 64 * 2 + blk_off((lc * 16) / 32, y, x, H, W) +
+                           (size_t)((lc * 16) % 32) * 2;
+                float o16[16];
+#pragma unroll
+                for (int ct = 0; ct < 4; ++ct)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) o16[ct * 4 + j] = fmaxf(acc[ct][j], 0.f);
+                *reinterpret_cast<uint4*>(op) = chunk_pack<__bf16>(o16);
+                *reinterpret_cast<uint4*>(op + 16) = chunk_pack<__bf16>(o16 + 8);
+            }
+        }
+    }
+}
+
 // thread = (plane, output pixel, 16-byte chunk); blocked layout in and out
 template <typename T>
 __global__ __launch_bounds__(256) void maxpool2_kernel(const T* __restrict__ src,

@@ -71,13 +71,13 @@ def conv_flops(h, w):
     return tot + 2.0 * h * w * 64
 
 
-def make_bench_model(precision: str, seed: int = 0) -> "P.FrameInterpolationUNet":
+def make_bench_model(precision: str, seed: int = 0, frame_channels: int = 1) -> "P.FrameInterpolationUNet":
     """Random-init network of the benchmark: He-scaled conv weights and non-trivial BatchNorm
     statistics so activations stay O(1) through all 19 layers (torch's default init + identity BN
     decays towards zero, and near-zero MFMA operands run at a higher clock than real data: never
     bench on those).  Same weights on every rank."""
     torch.manual_seed(seed)
-    model = P.FrameInterpolationUNet(bilinear=True, precision=precision)
+    model = P.FrameInterpolationUNet(bilinear=True, precision=precision, frame_channels=frame_channels)
     with torch.no_grad():
         for name, prm in model.named_parameters():
             if prm.dim() == 4 and prm.shape[-1] == 3:
@@ -506,7 +506,12 @@ def main():
             dist.destroy_process_group()
         return
 
-    cpu_baseline = parity = fp32 = None
+    cpu_baseline = parity = fp32 = rgb = None
+    if world == 1 and default_workload and not args.no_fp32:
+        try:
+            rgb = rgb_leg(dev)
+        except Exception as e:  # an extra leg must never cost the headline line
+            rgb = {"error": f"{type(e).__name__}: {e}"}
     if world == 1 and default_workload and not args.no_fp32:
         try:
             fp32 = fp32_legs(dev)
@@ -515,7 +520,7 @@ def main():
     if world == 1 and not args.no_cpu_baseline:
         cpu_baseline, parity = cpu_legs(dev, args.precision)
     print(json.dumps(headline(args, world, elapsed, rows, nfw, default_workload, video_res, tile_res,
-                              cpu_baseline, parity, fp32, power)))
+                              cpu_baseline, parity, fp32, power, rgb)))
     if dist is not None:
         dist.destroy_process_group()
 
@@ -590,6 +595,51 @@ def dominant_kernel(rows, precision):
     return dom_name, dom, achieved
 
 
+def rgb_leg(dev, steps=10, warm=2):
+    """The 6 -> 3 RGB variant the north star's wording describes (`UNet(n_channels=6, n_classes=3)`, unet.py:66; SURVEY
+    section 0: "report both"): batch 8 of 1080p RGB pairs, bf16, same protocol as the headline (inputs resident, HIP
+    events around the timed forwards on the launch stream).  +0.38 % FLOPs over the gray network; the stem
+    runs as its own kernel here (the fused stem exists for the gray network only), so the 64-channel stem output
+    makes one extra round trip through HBM."""
+    model = make_bench_model("bf16", frame_channels=3).to(dev).eval()
+    b, h, w = 8, 1080, 1920
+    gen = torch.Generator(device=dev).manual_seed(3)
+    f1 = torch.rand(b, 3, h, w, device=dev, generator=gen) * 2 - 1
+    f2 = torch.rand(b, 3, h, w, device=dev, generator=gen) * 2 - 1
+    for _ in range(warm):
+        model(f1, f2)
+    model._ctx.profile_enable(True)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize()
+    e0.record()
+    for _ in range(steps):
+        model(f1, f2)
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / steps
+    _, rows = model._ctx.profile_read()
+    model._ctx.profile_enable(False)
+    fps = b / (ms * 1e-3)
+    flops = conv_flops(h, w) + 2.0 * h * w * (4 * 64 * 9 + 2 * 64)   # SURVEY 8d: RGB adds 2 H W (4*64*9 + 2*64)
+    # parity of this variant on a small odd-sized pair against the CPU oracle (same seeded weights)
+    from oracle import unet_oracle as O
+    sd = {k: v.detach().cpu() for k, v in model.state_dict().items()}
+    g = torch.Generator().manual_seed(5)
+    s1, s2 = torch.rand(1, 3, 135, 240, generator=g) * 2 - 1, torch.rand(1, 3, 135, 240, generator=g) * 2 - 1
+    ref = O.unet_forward(sd, s1, s2)
+    out16 = model(s1.to(dev), s2.to(dev)).cpu()
+    model.precision = "fp32"
+    out32 = model(s1.to(dev), s2.to(dev)).cpu()
+    return {"value": round(fps, 2), "unit": "frames/s", "ms_per_step": round(ms, 3), "steps": steps, "warmup": warm, "dtype": "bf16",
+            "workload": "batch=8 1920x1080 synthetic RGB frame pairs, UNet(6->3, bilinear), bf16 MFMA conv path",
+            "whole_forward_tflops": round(fps * flops / 1e12, 1),
+            "whole_forward_mfma_frac": round(fps * flops / 1e12 / PEAK_TFLOPS["bf16"], 4),
+            "stages_ms": [[n, round(t, 3)] for n, t, _ in rows],
+            "parity_135x240": {"fp32_max_abs_vs_cpu_ref": round(float((out32 - ref).abs().max()), 8),
+                               "bf16_rel_l2_vs_cpu_ref": round(float((out16 - ref).norm() / ref.norm()), 6),
+                               "out_absmax": round(float(ref.abs().max()), 4)}}
+
+
 def fp32_legs(dev):
     """The reference's own arithmetic (fp32) on the driver-timed line: BASELINE configs[1] (batch 16 of
     256x256 pairs, SURVEY 8d config 2 protocol: 10 warm-up + 50 timed, HIP events around the forwards on
@@ -633,7 +683,7 @@ def fp32_legs(dev):
 
 
 def headline(args, world, elapsed, rows, nfw, default_workload, video_res, tile_res, cpu_baseline, parity,
-             fp32=None, power=None):
+             fp32=None, power=None, rgb=None):
     b, h, w = args.batch, args.height, args.width
     fps = world * b * args.steps / elapsed
     ms_step = elapsed / args.steps * 1e3
@@ -694,6 +744,8 @@ def headline(args, world, elapsed, rows, nfw, default_workload, video_res, tile_
         result["parity"] = parity
     if fp32 is not None:
         result["fp32"] = fp32
+    if rgb is not None:
+        result["rgb_6to3"] = rgb
     if power is not None:
         result["power"] = power
         if power.get("mfma_peak_at_sclk_tflops"):

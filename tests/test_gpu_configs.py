@@ -111,8 +111,9 @@ def test_rgb_fp32_matches_reference_unet_6_3(dev, golden_dir, name):
 
 
 def test_rgb_bf16_odd_size_fused_unfused_oracle(dev):
-    """conv3x3_first_kernel<bf16,3> and the 3-class fused head in bf16 (never run by round 1's
-    tests), at an odd size (floor-pool + asymmetric F.pad), fused vs unfused vs oracle."""
+    """The RGB stem (round 4: stem_rgb_split_kernel, hi + lo split bf16 MFMA) and the 3-class fused head in bf16,
+    at an odd size (floor-pool + asymmetric F.pad), fused vs unfused vs oracle; the stem's own output against the
+    oracle's first activation to bf16 rounding (its arithmetic is ~2^-16 relative before that rounding)."""
     m, sd = _rgb_model(dev, 77, "bf16")
     f1, f2 = O.make_frames(33, 2, 45, 71, c=3)
     ref = O.unet_forward(sd, f1, f2)
@@ -127,6 +128,17 @@ def test_rgb_bf16_odd_size_fused_unfused_oracle(dev):
         assert ((o - ref).norm() / ref.norm()).item() <= 2e-2
         assert (o - ref).abs().max().item() <= 0.04 * rng
     m.set_options()
+    # the stem alone: relu(bn(conv(cat(f1, f2)))) of the oracle vs tap 0 (dither off: it perturbs the INPUT by +-2^-9)
+    m.set_options(no_dither=True)
+    acts_nd, _ = m.debug_activations(f1.to(dev), f2.to(dev), taps=[0])
+    m.set_options()
+    taps = {}
+    O.unet_forward(sd, f1, f2, taps=taps)
+    k0 = "unet.inc.double_conv.0"
+    got0, want0 = acts_nd[k0].cpu().float(), taps[k0]
+    err = (got0 - want0).abs()
+    assert got0.shape == want0.shape
+    assert (err <= (2.0 ** -8 + 2.0 ** -13) * want0.abs() + 5e-4).all(), float(err.max())   # one bf16 rounding (<= 2^-8 relative) + the split arithmetic (2^-16 of the summed |terms|, which also decides the sign next to relu's kink)
     # RGB has no fused stem, so in bf16 all 18 stage outputs are bit-identical fused vs unfused
     for k in outs[False][0]:
         assert torch.equal(outs[False][0][k], outs[True][0][k]), k
