@@ -8,12 +8,12 @@ from .inference import (  # noqa: F401
     sequence_pair_fn,
 )
 from .serving import InterpolationService  # noqa: F401
-from . import evaluation, metrics, serving, synthetic, tiling, transport, video  # noqa: F401
+from . import evaluation, metrics, optical_flow, serving, synthetic, tiling, transport, video  # noqa: F401
 
 __all__ = [
     "FrameInterpolationUNet", "GraphedForward", "UNet", "count_parameters", "FrameInterpolator",
     "generate_multiple_intermediate_frames", "interpolate_frames", "interpolate_sequence",
-    "interpolate_sequence_host", "sequence_pair_fn", "transport",
+    "interpolate_sequence_host", "sequence_pair_fn", "transport", "optical_flow",
     "load_model", "postprocess_image", "preprocess_image", "evaluation", "metrics", "tiling", "video",
     "InterpolationService", "serving", "synthetic",
 ]

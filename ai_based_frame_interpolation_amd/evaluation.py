@@ -4,13 +4,14 @@ middle frame with each method, turn it into the uint8 image `postprocess_image` 
 (inference.py:54-61), and score it against the ground truth with PSNR and SSIM (skimage definitions,
 data_range 255: metrics.py).  The reference does the scoring on the host, one frame at a time.
 
-Methods: "unet" (the HIP forward, `forward_u8`) and "linear" ((f0 + f1) / 2 on the [-1, 1] tensors,
-evaluation_simple.py:71-74).  The reference's third method, "optical_flow" (evaluation_simple.py:76-103),
-IS OpenCV: `cv2.calcOpticalFlowFarneback` + `cv2.remap`.  It is not restated here (nothing in this
-image could pin a restatement of Farneback); when `cv2` is importable the method calls OpenCV itself on
-the host with the reference's parameters and only the scoring runs on the device, otherwise asking for
-it raises.  Statistics per method follow evaluation_simple.py:226-242 (numpy mean / population std /
-min / max).
+Methods: "unet" (the HIP forward, `forward_u8`), "linear" ((f0 + f1) / 2 on the [-1, 1] tensors,
+evaluation_simple.py:71-74) and "optical_flow" (evaluation_simple.py:76-103).  The third one IS OpenCV in the
+reference: `cv2.calcOpticalFlowFarneback` + `cv2.remap`.  When `cv2` is importable it is called itself, on the
+host, with the reference's parameters; otherwise (every image this code has run on) the method runs
+`optical_flow.py`, a torch RESTATEMENT of Farneback's algorithm and of remap's fixed-point sampling that is
+**parity-unpinned against OpenCV** (no OpenCV here to compare with, no fixtures in the reference) - the result
+dict says which backend produced the numbers (`optical_flow_backend`).  Only the scoring runs in HIP kernels.
+Statistics per method follow evaluation_simple.py:226-242 (numpy mean / population std / min / max).
 """
 from __future__ import annotations
 
@@ -19,24 +20,35 @@ from typing import Dict, Iterable
 import numpy as np
 import torch
 
-from . import _native, metrics
+from . import _native, metrics, optical_flow
 
-METHODS = ("unet", "linear")          # always available
-ALL_METHODS = METHODS + ("optical_flow",)  # the third one needs OpenCV
+METHODS = ("unet", "linear")          # the default pair (no flow estimation)
+ALL_METHODS = METHODS + ("optical_flow",)  # the reference's three (evaluation_simple.py:134-244)
+
+
+def optical_flow_backend() -> str:
+    """Which implementation the "optical_flow" method uses in this process."""
+    try:
+        import cv2  # type: ignore  # noqa: F401
+        return "opencv"
+    except ImportError:
+        return "restated (ai_based_frame_interpolation_amd.optical_flow; parity unpinned against OpenCV)"
 
 
 def _optical_flow_u8(f0: torch.Tensor, f1: torch.Tensor) -> torch.Tensor:
-    """optical_flow_interpolation_baseline (evaluation_simple.py:76-103) through OpenCV itself, frame by
-    frame on the host: Farneback flow f0 -> f1 (pyr_scale 0.5, 3 levels, winsize 15, 3 iterations,
-    poly_n 5, poly_sigma 1.1), frame 0 sampled at (x, y) + flow/2 clipped to the image, bilinear,
-    replicated border.  uint8 [N,1,H,W] in, uint8 [N,1,H,W] on the same device out."""
-    try:
-        import cv2  # type: ignore
-    except ImportError as e:
-        raise NotImplementedError("the optical-flow baseline is OpenCV's Farneback + remap "
-                                  "(evaluation_simple.py:76-103); OpenCV is not available here") from e
+    """optical_flow_interpolation_baseline (evaluation_simple.py:76-103), frame by frame: Farneback flow
+    f0 -> f1 (pyr_scale 0.5, 3 levels, winsize 15, 3 iterations, poly_n 5, poly_sigma 1.1), frame 0 sampled at
+    (x, y) + flow/2 clipped to the image, bilinear, replicated border (as written in the reference: this moves
+    the content AGAINST its motion, so on translating content the baseline scores below the linear blend).
+    uint8 [N,1,H,W] in, uint8 [N,1,H,W] on the same device out.  OpenCV itself when importable, else the
+    restatement of optical_flow.py on the frames' own device."""
     if f0.shape[1] != 1:
         raise RuntimeError("the optical-flow baseline is defined on grayscale frames (one channel)")
+    try:
+        import cv2  # type: ignore
+    except ImportError:
+        return torch.stack([optical_flow.optical_flow_interpolation_baseline(f0[i, 0], f1[i, 0])
+                            for i in range(f0.shape[0])]).unsqueeze(1)
     a_all, b_all = f0[:, 0].cpu().numpy(), f1[:, 0].cpu().numpy()
     out = np.empty_like(a_all)
     for i in range(a_all.shape[0]):
@@ -74,12 +86,8 @@ def evaluate_triplets(model, frame_t0: torch.Tensor, frame_t1: torch.Tensor, gro
     for m in methods:
         if m not in ALL_METHODS:
             raise ValueError(f"unknown method {m!r}; choose from {ALL_METHODS}")
-    if "optical_flow" in methods:
-        try:
-            import cv2  # noqa: F401
-        except ImportError as e:
-            raise NotImplementedError("the optical-flow baseline is OpenCV's Farneback + remap "
-                                      "(evaluation_simple.py:76-103); OpenCV is not available here") from e
+    if "optical_flow" in methods and frame_t0.shape[1] != 1:
+        raise RuntimeError("the optical-flow baseline is defined on grayscale frames (one channel)")
     if not (frame_t0.shape == frame_t1.shape == ground_truth.shape) or frame_t0.dim() != 4:
         raise RuntimeError("expected three uint8 [N, C, H, W] tensors of equal shape")
     n = frame_t0.shape[0]
@@ -95,6 +103,8 @@ def evaluate_triplets(model, frame_t0: torch.Tensor, frame_t1: torch.Tensor, gro
             per[m]["ssim"].append(metrics.ssim_u8(pred, gt).mean(dim=1))
     out = {"total_triplets": n, "successful_evaluations": n, "methods": list(methods),
            "metrics_by_method": {}, "per_triplet": {}}
+    if "optical_flow" in methods:
+        out["optical_flow_backend"] = optical_flow_backend()
     for m in methods:
         ps = torch.cat(per[m]["psnr"]).cpu().numpy() if n else np.zeros(0)
         ss = torch.cat(per[m]["ssim"]).cpu().numpy() if n else np.zeros(0)

@@ -351,3 +351,80 @@ def test_y4m_round_trip_and_header_parsing(tmp_path):
     bad.write_bytes(b"RIFF....")
     with pytest.raises(ValueError):
         IO.read_y4m(str(bad))
+
+
+# ---- optical_flow.py: restatement of the reference's third evaluator method (parity unpinned against OpenCV) ----
+def _flow_texture(h, w, dx, dy, seed=0):
+    """smooth random texture sampled at (x - dx, y - dy): the content moves by (+dx, +dy)"""
+    import torch.nn.functional as F
+    from ai_based_frame_interpolation_amd import optical_flow as OF
+    g = torch.Generator().manual_seed(seed)
+    x = torch.rand(h + 40, w + 40, generator=g)
+    k = OF._gauss_kernel_cv(19, 3.0, torch.float32, "cpu")
+    big = F.conv2d(F.conv2d(x[None, None], k.view(1, 1, 1, -1)), k.view(1, 1, -1, 1))[0, 0]
+    big = (big - big.min()) / (big.max() - big.min())
+    H, W = big.shape
+    ys, xs = torch.meshgrid(torch.arange(h, dtype=torch.float32), torch.arange(w, dtype=torch.float32), indexing="ij")
+    grid = torch.stack([(xs + 10 - dx) / (W - 1) * 2 - 1, (ys + 10 - dy) / (H - 1) * 2 - 1], -1)[None]
+    out = F.grid_sample(big[None, None], grid, mode="bicubic", align_corners=True)[0, 0]
+    return (out * 255).round().clamp(0, 255).to(torch.uint8)
+
+
+@pytest.mark.parametrize("dx,dy", [(2.5, -1.5), (0.0, 3.0), (-4.0, 0.5)])
+def test_farneback_restatement_recovers_a_translation(dx, dy):
+    """The behaviour the algorithm must have (cv2's convention: prev(y, x) ~ next(y + flow_y, x + flow_x)): a
+    smooth texture translated by (dx, dy) yields that flow in the interior, to a few hundredths of a pixel."""
+    from ai_based_frame_interpolation_amd import optical_flow as OF
+    a, b = _flow_texture(96, 128, 0, 0), _flow_texture(96, 128, dx, dy)
+    flow = OF.calc_optical_flow_farneback(a, b)
+    assert flow.shape == (96, 128, 2) and flow.dtype == torch.float32
+    core = flow[20:-20, 20:-20]
+    assert abs(core[..., 0].mean().item() - dx) < 0.05 and abs(core[..., 1].mean().item() - dy) < 0.05
+    assert core[..., 0].std().item() < 0.05 and core[..., 1].std().item() < 0.05
+    # identical frames: no motion (the last row / column count as "outside" in the update step, as in OpenCV,
+    # which leaves a few hundredths of a pixel of flow in the window next to them)
+    z = OF.calc_optical_flow_farneback(a, a)
+    assert z[20:-20, 20:-20].abs().max().item() < 1e-3 and z.abs().max().item() < 0.2
+
+
+def test_optical_flow_baseline_is_the_references_formula():
+    """evaluation_simple.py:92-101 as written: frame 0 sampled at grid + flow / 2 (clipped), i.e. the content is
+    moved by -flow / 2 - AGAINST its motion; so on a translating texture the baseline equals frame 0 shifted by
+    -d / 2 and scores BELOW the linear blend.  remap with integer coordinates is the identity; fractional
+    coordinates follow the 5-bit fixed-point bilinear rule."""
+    from ai_based_frame_interpolation_amd import optical_flow as OF
+    h, w, dx, dy = 96, 128, 4.0, 2.0
+    a, b = _flow_texture(h, w, 0, 0), _flow_texture(h, w, dx, dy)
+    out = OF.optical_flow_interpolation_baseline(a, b)
+    assert out.shape == a.shape and out.dtype == torch.uint8
+    back = _flow_texture(h, w, -dx / 2, -dy / 2)            # frame 0's content moved by -d/2
+    true_mid = _flow_texture(h, w, dx / 2, dy / 2)
+    c = (slice(16, -16), slice(16, -16))
+    mse = lambda p, q: ((p[c].float() - q[c].float()) ** 2).mean().item()
+    assert mse(out, back) < 2.0                               # ~1 code rms: it IS the backward-shifted frame
+    lin = ((a.float() + b.float()) / 2).to(torch.uint8)
+    assert mse(out, true_mid) > mse(lin, true_mid)            # the reference's quirk, kept
+    ys, xs = torch.meshgrid(torch.arange(h, dtype=torch.float32), torch.arange(w, dtype=torch.float32), indexing="ij")
+    assert torch.equal(OF.remap_bilinear_u8(a, xs, ys), a)
+    half = OF.remap_bilinear_u8(a, (xs + 0.5).clamp(0, w - 1), ys)
+    want = ((a[:, :-1].long() * 16384 + a[:, 1:].long() * 16384 + 16384) >> 15).to(torch.uint8)
+    assert torch.equal(half[:, :-1], want)
+    q = OF.remap_bilinear_u8(a, (xs - 7.3).clamp(0, w - 1), (ys + 200).clamp(0, h - 1))   # clipped: replicated border
+    assert torch.equal(q[:, :7], a[-1:, :1].expand(h, 7))
+
+
+def test_evaluator_uses_the_restatement_without_opencv():
+    from ai_based_frame_interpolation_amd import evaluation
+    try:
+        import cv2  # noqa: F401
+        pytest.skip("OpenCV is installed: the evaluator calls it instead")
+    except ImportError:
+        pass
+    assert "parity unpinned" in evaluation.optical_flow_backend()
+    a, b = _flow_texture(64, 80, 0, 0, seed=2), _flow_texture(64, 80, 3.0, 0.0, seed=2)
+    f0, f1 = torch.stack([a, b])[:, None], torch.stack([b, a])[:, None]
+    out = evaluation._optical_flow_u8(f0, f1)
+    from ai_based_frame_interpolation_amd import optical_flow as OF
+    assert out.shape == f0.shape and torch.equal(out[0, 0], OF.optical_flow_interpolation_baseline(a, b))
+    with pytest.raises(RuntimeError, match="grayscale"):
+        evaluation._optical_flow_u8(f0.repeat(1, 3, 1, 1), f1.repeat(1, 3, 1, 1))

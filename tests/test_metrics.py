@@ -132,8 +132,13 @@ def test_evaluate_triplets_matches_host_scoring(seeded_sd):
         assert st["average_psnr"] == pytest.approx(np.mean(ps), abs=1e-9)
         assert st["std_ssim"] == pytest.approx(np.std(ss), abs=1e-9)
         assert st["min_psnr"] == pytest.approx(ps.min(), abs=1e-9) and st["max_ssim"] == pytest.approx(ss.max(), abs=1e-9)
-    with pytest.raises(NotImplementedError, match="OpenCV"):
-        evaluation.evaluate_triplets(m, f0.to(dev), f1.to(dev), gt.to(dev), methods=("optical_flow",))
+    # the reference's third method: OpenCV when importable, else the restatement of optical_flow.py (parity
+    # unpinned against OpenCV; tests/test_host.py pins its behaviour) - scored on the device like the others
+    r3 = evaluation.evaluate_triplets(m, f0.to(dev), f1.to(dev), gt.to(dev), methods=evaluation.ALL_METHODS, batch=2)
+    assert r3["methods"] == ["unet", "linear", "optical_flow"] and "optical_flow_backend" in r3
+    of = r3["per_triplet"]["optical_flow"]
+    assert of["psnr"].shape == (n,) and np.isfinite(of["psnr"]).all() and np.isfinite(of["ssim"]).all()
+    assert np.allclose(r3["per_triplet"]["unet"]["psnr"], res["per_triplet"]["unet"]["psnr"])
 
 
 # ---- Gaussian-window SSIM / CombinedLoss of the training loss (train.py:18-87) --------------------
