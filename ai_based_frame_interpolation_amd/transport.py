@@ -74,7 +74,8 @@ def batch_isend_irecv(ops: List[dist.P2POp]) -> list:
             host.copy_(op.tensor, non_blocking=True)
         staged.append(host)
     if any(op.op is dist.isend for op in ops):
-        torch.cuda.current_stream(ops[0].tensor.device).synchronize()
+        for dev in {op.tensor.device for op in ops if op.op is dist.isend and op.tensor.is_cuda}:
+            torch.cuda.current_stream(dev).synchronize()
     for op, host in zip(ops, staged):
         w = op.op(host, group=op.group, tag=op.tag, **_peer_kwargs(op))
         works.append(_SendWork(w, host) if op.op is dist.isend else _RecvWork(w, host, op.tensor))
