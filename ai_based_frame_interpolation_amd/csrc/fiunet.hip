@@ -48,7 +48,11 @@ const char* const kBlockPrefix[9] = {
     "unet.inc", "unet.down1.maxpool_conv.1", "unet.down2.maxpool_conv.1",
     "unet.down3.maxpool_conv.1", "unet.down4.maxpool_conv.1", "unet.up1.conv", "unet.up2.conv",
     "unet.up3.conv", "unet.up4.conv"};
-const int kCout[NCONV] = {64, 64, 128, 128, 256, 256, 512, 512, 512, 512, 512, 256, 256, 128, 128, 64, 64, 64};
+// output channels of the 18 convs: bilinear=True (factor 2, Up's DoubleConv has mid = in / 2; the only variant a reference
+// caller constructs) and bilinear=False (the constructor's default, unet.py:66,99: factor 1, down4 -> 1024, Up =
+// ConvTranspose2d(in, in / 2, 2, 2) + DoubleConv(in, out), unet.py:42-44)
+const int kCoutBil[NCONV] = {64, 64, 128, 128, 256, 256, 512, 512, 512, 512, 512, 256, 256, 128, 128, 64, 64, 64};
+const int kCoutCT[NCONV] = {64, 64, 128, 128, 256, 256, 512, 512, 1024, 1024, 512, 512, 256, 256, 128, 128, 64, 64};
 const int kLevel[NCONV] = {0, 0, 1, 1, 2, 2, 3, 3, 4, 4, 3, 3, 2, 2, 1, 1, 0, 0};
 // gather mode and sources (activation indices) of each conv; conv 0 is the fp32 stem kernel
 // SRC_POOL here means "reads MaxPool2d(2) of its source": the pooled tensor is written by the
@@ -139,6 +143,8 @@ struct Plan {
 // the fused stem / fused head leave activations 0 / 17 out altogether.
 struct PlanOpts {
     bool keep_all = false, unfused = false, fused_stem = false, fused_head = false, gather_up = false;
+    const int* cout = kCoutBil;   // architecture: output channels per conv
+    bool convt = false;           // bilinear=False: the upsampled half is a ConvTranspose2d output, always materialised
 };
 
 // A concat conv whose output spans several 128-cout tiles would bilinearly interpolate every input
@@ -146,9 +152,11 @@ struct PlanOpts {
 // (upsample_kernel) and gathered by plain LDS-DMA like the skip half.  bf16 only: on the fp32 matrix
 // cores the interpolation is small beside the 16x slower MFMAs, and the tensor twice as big.
 // Small problems (launch-bound, K-split) keep the fused gather: `pixels` = B x H x W at the stage's level.
-inline bool materialise_up(int stage, int precision, bool unfused, long long pixels)
+inline bool materialise_up(int stage, int precision, bool unfused, long long pixels, const int* cout = kCoutBil,
+                           bool convt = false)
 {
-    return precision == FIUNET_BF16 && !unfused && kMode[stage] == SRC_CONCAT_UP && kCout[stage] >= 256 &&
+    if (convt) return kMode[stage] == SRC_CONCAT_UP;   // there is no "interpolate in the gather" for a transposed conv
+    return precision == FIUNET_BF16 && !unfused && kMode[stage] == SRC_CONCAT_UP && cout[stage] >= 256 &&
            pixels >= 65536;
 }
 
@@ -171,21 +179,23 @@ bool make_plan(int B, int H, int W, int precision, const PlanOpts& o, Plan& p)
         for (int j = i + 1; j < NCONV; ++j)
             if (kSrc0[j] == i || kSrc1[j] == i) last = j;
         if (i == NCONV - 1 || o.keep_all) last = END;
-        bufs.push_back({align256((size_t)B * p.hs[kLevel[i]] * p.ws[kLevel[i]] * kCout[i] * es), i, last,
+        bufs.push_back({align256((size_t)B * p.hs[kLevel[i]] * p.ws[kLevel[i]] * o.cout[i] * es), i, last,
                         &p.act_off[i]});
     }
     for (int k = 0; k < 4; ++k) {  // MaxPool2d(2) of x1..x4: written by conv 2k+1, read by conv 2k+2
-        bufs.push_back({align256((size_t)B * p.hs[k + 1] * p.ws[k + 1] * kCout[2 * k + 1] * es), 2 * k + 1,
+        bufs.push_back({align256((size_t)B * p.hs[k + 1] * p.ws[k + 1] * o.cout[2 * k + 1] * es), 2 * k + 1,
                         o.keep_all ? END : 2 * k + 2, &p.pool_off[k]});
     }
     for (int i = 0; i < NCONV; ++i) {
         p.up_off[i] = 0;
-        if (materialise_up(i, precision, o.unfused || o.gather_up, (long long)B * p.hs[kLevel[i]] * p.ws[kLevel[i]]))
-            bufs.push_back({align256((size_t)B * p.hs[kLevel[i]] * p.ws[kLevel[i]] * kCout[kSrc1[i]] * es), i,
+        if (materialise_up(i, precision, o.unfused || o.gather_up, (long long)B * p.hs[kLevel[i]] * p.ws[kLevel[i]], o.cout,
+                           o.convt))
+            bufs.push_back({align256((size_t)B * p.hs[kLevel[i]] * p.ws[kLevel[i]] *
+                                     (o.convt ? o.cout[kSrc1[i]] / 2 : o.cout[kSrc1[i]]) * es), i,
                             o.keep_all ? END : i, &p.up_off[i]});
     }
     p.scratch_off = 0;
-    if (o.unfused)  // ablation path: concat tensor (<= 128 ch at level 0), rewritten by every Up block
+    if (o.unfused && !o.convt)  // ablation path: concat tensor (<= 128 ch at level 0), rewritten by every Up block
         bufs.push_back({align256((size_t)B * H * W * 128 * es), 0, END, &p.scratch_off});
     bufs.push_back({kSlabBytes, 0, END, &p.slab_off});  // split-K partial sums (small problems)
     std::stable_sort(bufs.begin(), bufs.end(), [](const Buf& a, const Buf& b) { return a.first < b.first; });
@@ -216,6 +226,9 @@ bool make_plan(int B, int H, int W, int precision, const PlanOpts& o, Plan& p)
 struct fiunet_ctx {
     int device = 0;
     int cf = 1;  // channels per frame
+    bool bilinear = true;          // false: ConvTranspose2d decoder (unet.py:42-44)
+    const int* cout = kCoutBil;    // output channels per conv of this architecture
+    struct { int cin = 0, cout = 0; void* w_f32 = nullptr; void* w_bf16 = nullptr; float* bias = nullptr; } convt[4];
     unsigned flags = 0;
     bool loaded = false;
     ConvWeights conv[NCONV];
@@ -395,6 +408,8 @@ PlanOpts plan_opts(const fiunet_ctx* ctx, int H, int W, int precision)
     o.fused_stem = precision == FIUNET_BF16 && ctx->cf == 1 && !o.unfused && !o.keep_all &&
                    ctx->stem_w_split != nullptr && prefer_wide(H, W, 16, 32, 32, 16);
     o.fused_head = !o.unfused && !o.keep_all;  // OutConv reduced in the last conv's epilogue
+    o.cout = ctx->cout;
+    o.convt = !ctx->bilinear;
     return o;
 }
 
@@ -525,7 +540,7 @@ int forward_impl(fiunet_ctx* ctx, const float* f1, const float* f2, float* out, 
         a.dst = act(i);
         int mode = kMode[i];
         a.src0 = act(kSrc0[i]);
-        a.C0 = kCout[kSrc0[i]];
+        a.C0 = ctx->cout[kSrc0[i]];
         if (mode == SRC_POOL) {
             // MaxPool2d(2) of the source (unet.py:28): already materialised by the producer's
             // epilogue (EPI_POOL below), or by maxpool2_kernel right here on the ablation path
@@ -540,7 +555,7 @@ int forward_impl(fiunet_ctx* ctx, const float* f1, const float* f2, float* out, 
             mode = SRC_DIRECT;
         } else if (mode == SRC_CONCAT_UP) {
             a.src1 = act(kSrc1[i]);
-            a.C1 = kCout[kSrc1[i]];
+            a.C1 = ctx->cout[kSrc1[i]];
             a.lowH = p.hs[lv + 1]; a.lowW = p.ws[lv + 1];
             // vertical mapping in whole-image coordinates (a band starts at a multiple of 16 rows,
             // so its level-l tensors start at global row y_origin >> l)
@@ -552,6 +567,25 @@ int forward_impl(fiunet_ctx* ctx, const float* f1, const float* f2, float* out, 
             // aten area_pixel_compute_scale, align_corners=True: (in - 1) / (out - 1) in fp32
             a.sy = 2 * a.lowHg > 1 ? (float)(a.lowHg - 1) / (float)(2 * a.lowHg - 1) : 0.f;
             a.sx = 2 * a.lowW > 1 ? (float)(a.lowW - 1) / (float)(2 * a.lowW - 1) : 0.f;
+        }
+        if (mode == SRC_CONCAT_UP && !ctx->bilinear) {
+            // bilinear=False (unet.py:42-44): ConvTranspose2d(C, C / 2, 2, 2) of the low-res tensor + F.pad, written once
+            // as a full-resolution tensor; the conv then gathers two full-resolution sources (skip planes, then these)
+            const auto& ct = ctx->convt[(i - 10) / 2];
+            T* up = (T*)(ws + p.up_off[i]);
+            ConvTArgs c;
+            std::memset(&c, 0, sizeof(c));
+            c.low = a.src1; c.wgt = bf16 ? ct.w_bf16 : ct.w_f32; c.bias = ct.bias; c.dst = up;
+            c.B = B; c.H = a.H; c.W = a.W; c.lowH = a.lowH; c.lowW = a.lowW; c.Cin = ct.cin; c.Cout = ct.cout;
+            c.padT = a.padT; c.padL = a.padL; c.upOffY = a.upOffY; c.lowOffY = a.lowOffY; c.lowHg = a.lowHg;
+            if (a.C1 != ct.cin) return fail(FIUNET_ERR_INVALID_ARG, "internal: transposed-conv channel plan mismatch");
+            if (y_origin != 0 || Hg != H || a.H != 2 * a.lowH || a.W != 2 * a.lowW)   // F.pad rows / columns (and a band's edges)
+                HIP_TRY(hipMemsetAsync(up, 0, (size_t)B * a.H * a.W * ct.cout * sizeof(T), s));
+            const long long units = (long long)B * a.lowH * ((a.lowW + 31) / 32) * (ct.cout / 64);   // 32 pixels per wave
+            hipLaunchKernelGGL((convt2x2_kernel<T>), dim3((unsigned)std::min<long long>((units + 3) / 4, 256 * 16)),
+                               dim3(256), 0, s, c);
+            HIP_TRY(hipGetLastError());
+            a.src1 = up; a.C1 = ct.cout; mode = SRC_DIRECT;
         }
         if (a.C0 + a.C1 != cw.cin) return fail(FIUNET_ERR_INVALID_ARG, "internal: channel plan mismatch");
         if (i == 1 && fuse_stem) {
@@ -568,7 +602,7 @@ int forward_impl(fiunet_ctx* ctx, const float* f1, const float* f2, float* out, 
             a.src0 = scratch; a.C0 = a.C0 + a.C1; a.C1 = 0; a.src1 = nullptr; mode = SRC_DIRECT;
         }
         if (mode == SRC_CONCAT_UP &&
-            materialise_up(i, bf16 ? FIUNET_BF16 : FIUNET_FP32, unfused || po.gather_up, (long long)B * a.H * a.W)) {
+            materialise_up(i, bf16 ? FIUNET_BF16 : FIUNET_FP32, unfused || po.gather_up, (long long)B * a.H * a.W, ctx->cout)) {
             T* up = (T*)(ws + p.up_off[i]);
             const dim3 grid((unsigned)((a.W * 4 + 255) / 256), (unsigned)((a.H + UPS_ROWS - 1) / UPS_ROWS),
                             (unsigned)(B * (a.C1 / Elem<T>::PL)));
@@ -622,10 +656,6 @@ int fiunet_create(fiunet_ctx** out_ctx, int device_id, int frame_channels, int b
     *out_ctx = nullptr;
     if (frame_channels != 1 && frame_channels != 3)
         return fail(FIUNET_ERR_INVALID_ARG, "frame_channels must be 1 (gray) or 3 (RGB)");
-    if (!bilinear)
-        return fail(FIUNET_ERR_UNSUPPORTED,
-                    "bilinear=False (ConvTranspose2d decoder) is not built; every reference caller "
-                    "constructs bilinear=True");
     int ndev = 0;
     HIP_TRY(hipGetDeviceCount(&ndev));
     if (device_id < 0 || device_id >= ndev) return fail(FIUNET_ERR_INVALID_ARG, "bad device_id");
@@ -633,6 +663,8 @@ int fiunet_create(fiunet_ctx** out_ctx, int device_id, int frame_channels, int b
     if (!c) return fail(FIUNET_ERR_INVALID_ARG, "out of host memory");
     c->device = device_id;
     c->cf = frame_channels;
+    c->bilinear = bilinear != 0;
+    c->cout = c->bilinear ? kCoutBil : kCoutCT;
     *out_ctx = c;
     return FIUNET_OK;
 }
@@ -680,10 +712,11 @@ int fiunet_load_weights(fiunet_ctx* ctx, int n, const char* const* names,
         const std::string pre = std::string(kBlockPrefix[blk]) + ".double_conv.";
         const std::string wk = pre + (second ? "3" : "0") + ".weight";
         const std::string bn = pre + (second ? "4" : "1");
+        const int* kCout = ctx->cout;
         const int cout = kCout[i];
         int cin;
         if (i == 0) cin = cin0;
-        else if (kMode[i] == SRC_CONCAT_UP) cin = kCout[kSrc0[i]] + kCout[kSrc1[i]];
+        else if (kMode[i] == SRC_CONCAT_UP) cin = kCout[kSrc0[i]] + (ctx->bilinear ? kCout[kSrc1[i]] : kCout[kSrc1[i]] / 2);
         else cin = kCout[kSrc0[i]];
         const float *w, *g, *be, *mu, *var;
         int rc;
@@ -759,6 +792,37 @@ int fiunet_load_weights(fiunet_ctx* ctx, int n, const char* const* names,
         }
         if ((rc = dev_upload(ctx, p32.data(), nel * 4, &cw.w_f32))) return rc;
         if ((rc = dev_upload(ctx, p16.data(), nel * 2, &cw.w_bf16))) return rc;
+    }
+    if (!ctx->bilinear) {
+        // ConvTranspose2d weights [Cin][Cout = Cin / 2][2][2] + bias (unet.py:43): packed per tap t = dy*2 + dx as
+        // [t][Cin/PL][Cout][PL], the conv kernels' weight layout with 4 taps (rows in natural cout order; the bf16 copy
+        // rounded to nearest - or with the per-filter error feedback, one filter = one (cout, tap))
+        for (int k = 0; k < 4; ++k) {
+            const int cin = ctx->cout[kSrc1[10 + 2 * k]], cout = cin / 2;
+            const std::string pre = "unet.up" + std::to_string(k + 1) + ".up.";
+            const float *w, *bi;
+            int rc;
+            if ((rc = get(pre + "weight", (int64_t)cin * cout * 4, &w))) return rc;
+            if ((rc = get(pre + "bias", cout, &bi))) return rc;
+            auto& ct = ctx->convt[k];
+            ct.cin = cin; ct.cout = cout;
+            const size_t nel = (size_t)4 * cin * cout;
+            std::vector<float> p32(nel);
+            std::vector<uint16_t> p16(nel);
+            for (int t = 0; t < 4; ++t)
+                for (int co = 0; co < cout; ++co) {
+                    double carry = 0.0;
+                    for (int ci = 0; ci < cin; ++ci) {
+                        const float wv = w[((size_t)ci * cout + co) * 4 + t];
+                        p32[(((size_t)t * (cin / 16) + ci / 16) * cout + co) * 16 + ci % 16] = wv;
+                        p16[(((size_t)t * (cin / 32) + ci / 32) * cout + co) * 32 + ci % 32] =
+                            rne_weights ? f32_to_bf16_rne(wv) : f32_to_bf16_feedback(wv, carry);
+                    }
+                }
+            if ((rc = dev_upload(ctx, p32.data(), nel * 4, &ct.w_f32))) return rc;
+            if ((rc = dev_upload(ctx, p16.data(), nel * 2, &ct.w_bf16))) return rc;
+            if ((rc = dev_upload(ctx, bi, (size_t)cout * 4, (void**)&ct.bias))) return rc;
+        }
     }
     {
         const float *w, *bi;
@@ -1103,7 +1167,7 @@ int fiunet_debug_read_activation(fiunet_ctx* ctx, const void* workspace, int B, 
                                             "activations share workspace bytes and are overwritten");
     if (!make_plan(B, H, W, precision, plan_opts(ctx, H, W, precision), p))
         return fail(FIUNET_ERR_BAD_SHAPE, "bad shape");
-    const int C = kCout[tap], h = p.hs[kLevel[tap]], w = p.ws[kLevel[tap]];
+    const int C = ctx->cout[tap], h = p.hs[kLevel[tap]], w = p.ws[kLevel[tap]];
     if (out_dims) { out_dims[0] = C; out_dims[1] = h; out_dims[2] = w; }
     const size_t n = (size_t)B * C * h * w;
     const char* src = (const char*)workspace + p.act_off[tap];

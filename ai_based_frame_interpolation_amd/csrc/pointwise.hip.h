@@ -254,6 +254,95 @@ __global__ __launch_bounds__(256) void stem_rgb_split_kernel(
     }
 }
 
+// ConvTranspose2d(Cin, Cout = Cin / 2, kernel 2, stride 2) + bias of the bilinear=False decoder
+// (/root/reference/model/unet.py:42-44,47) followed by F.pad to the skip tensor's size (unet.py:49-53), written as the
+// full-resolution blocked tensor that the next conv gathers as its second source (like the materialised bilinear
+// upsample).  With stride = kernel the four taps do not overlap: out[co][2y + dy][2x + dx] = bias[co] +
+// sum_ci x[ci][y][x] * W[ci][co][dy][dx], i.e. four pointwise GEMMs sharing their B operand.  One wave = 32 consecutive
+// low-res pixels of a row x 64 couts x 4 taps (32 accumulator tiles); both operands come straight from global memory
+// in MFMA fragment order (the blocked layouts already are: a lane's k-slots are one 16-B chunk of a plane record), no
+// LDS.  Not a tuned kernel: the variant is not on any benchmark line (no reference caller constructs it).
+struct ConvTArgs {
+    const void* low;     // [B][Cin/PL][lowH][lowW][PL]
+    const void* wgt;     // [4 taps = dy*2+dx][Cin/PL][Cout][PL]
+    const float* bias;   // [Cout]
+    void* dst;           // [B][Cout/PL][H][W][PL]; rows / columns outside the 2x extent are zeroed by the caller
+    int B, H, W, lowH, lowW, Cin, Cout;
+    int padT, padL;      // F.pad top / left, whole-image values
+    int upOffY, lowOffY, lowHg;   // row band of a taller image (fiunet_forward_strip); un-tiled: 0, 0, lowH
+};
+
+template <typename T>
+__global__ __launch_bounds__(256) void convt2x2_kernel(const ConvTArgs a)
+{
+    constexpr int PL = Elem<T>::PL;
+    constexpr int NPX = 2;   // 16-pixel fragments per wave: every weight fragment is used for 32 pixels
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int l15 = lane & 15, lc = lane >> 4;
+    const int xt = (a.lowW + 16 * NPX - 1) / (16 * NPX), cgs = a.Cout / 64, nplanes = a.Cin / PL;
+    const long long units = (long long)a.B * a.lowH * xt * cgs;
+    const size_t low_plane = (size_t)a.lowH * a.lowW * 64, out_plane = (size_t)a.H * a.W * 64;
+    for (long long u = (long long)blockIdx.x * 4 + wave; u < units; u += (long long)gridDim.x * 4) {
+        const int cg = (int)(u % cgs);
+        long long r = u / cgs;
+        const int tx = (int)(r % xt); r /= xt;
+        const int y = (int)(r % a.lowH), b = (int)(r / a.lowH);
+        const char* bsrc[NPX];
+#pragma unroll
+        for (int f = 0; f < NPX; ++f) {
+            const int xl = min(tx * 16 * NPX + f * 16 + l15, a.lowW - 1);
+            bsrc[f] = (const char*)a.low + (size_t)b * nplanes * low_plane + ((size_t)y * a.lowW + xl) * 64 + lc * 16;
+        }
+        const char* wsrc = (const char*)a.wgt + ((size_t)(cg * 64 + l15)) * 64 + lc * 16;
+        f32x4 acc[4][4][NPX];
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int ct = 0; ct < 4; ++ct)
+#pragma unroll
+                for (int f = 0; f < NPX; ++f) acc[t][ct][f] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int p = 0; p < nplanes; ++p) {
+            uint4 xb[NPX];
+#pragma unroll
+            for (int f = 0; f < NPX; ++f) xb[f] = *reinterpret_cast<const uint4*>(bsrc[f] + (size_t)p * low_plane);
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+#pragma unroll
+                for (int ct = 0; ct < 4; ++ct) {
+                    const uint4 wa = *reinterpret_cast<const uint4*>(
+                        wsrc + (((size_t)t * nplanes + p) * a.Cout + ct * 16) * 64);
+#pragma unroll
+                    for (int f = 0; f < NPX; ++f) mma_chunk<T>(acc[t][ct][f], wa, xb[f]);
+                }
+        }
+        // global row of this low-res row, and where its two output rows land in this band
+        const int yg = y + a.lowOffY;
+#pragma unroll
+        for (int f = 0; f < NPX; ++f) {
+            const int x = tx * 16 * NPX + f * 16 + l15;
+            if (x >= a.lowW || yg >= a.lowHg) continue;
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const int Y = 2 * yg + (t >> 1) + a.padT - a.upOffY, X = 2 * x + (t & 1) + a.padL;
+                if (Y < 0 || Y >= a.H || X < 0 || X >= a.W) continue;
+#pragma unroll
+                for (int ct = 0; ct < 4; ++ct) {
+                    const int co = cg * 64 + ct * 16 + lc * 4;   // MFMA row lc*4 + j of tile ct, natural cout order
+                    const float4 bi = *reinterpret_cast<const float4*>(a.bias + co);
+                    const f32x4 q = acc[t][ct][f];
+                    const float v[4] = {q[0] + bi.x, q[1] + bi.y, q[2] + bi.z, q[3] + bi.w};
+                    char* op = (char*)a.dst + (size_t)b * (a.Cout / PL) * out_plane + blk_off(co / PL, Y, X, a.H, a.W) +
+                               (size_t)(co % PL) * sizeof(T);
+                    if constexpr (sizeof(T) == 2)
+                        *reinterpret_cast<uint2*>(op) = make_uint2(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]));
+                    else
+                        *reinterpret_cast<float4*>(op) = make_float4(v[0], v[1], v[2], v[3]);
+                }
+            }
+        }
+    }
+}
+
 // thread = (plane, output pixel, 16-byte chunk); blocked layout in and out
 template <typename T>
 __global__ __launch_bounds__(256) void maxpool2_kernel(const T* __restrict__ src,

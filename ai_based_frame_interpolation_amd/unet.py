@@ -25,9 +25,14 @@ from . import _native
 # (attribute path of the DoubleConv holder, in, mid, out)
 _ENCODER = (("down1", 64, 128), ("down2", 128, 256), ("down3", 256, 512), ("down4", 512, 512))
 _DECODER = (("up1", 1024, 256), ("up2", 512, 128), ("up3", 256, 64), ("up4", 128, 64))
+# bilinear=False, the constructor's default (unet.py:66,76-81 with factor 1): down4 -> 1024, Up(in, out) =
+# ConvTranspose2d(in, in // 2, 2, 2) + DoubleConv(in, out)
+_ENCODER_CT = (("down1", 64, 128), ("down2", 128, 256), ("down3", 256, 512), ("down4", 512, 1024))
+_DECODER_CT = (("up1", 1024, 512), ("up2", 512, 256), ("up3", 256, 128), ("up4", 128, 64))
 
 #: channels / pyramid level of the 18 conv+BN+ReLU outputs, in state-dict order (debug taps)
 TAP_CHANNELS = (64, 64, 128, 128, 256, 256, 512, 512, 512, 512, 512, 256, 256, 128, 128, 64, 64, 64)
+TAP_CHANNELS_CT = (64, 64, 128, 128, 256, 256, 512, 512, 1024, 1024, 512, 512, 256, 256, 128, 128, 64, 64)
 TAP_LEVEL = (0, 0, 1, 1, 2, 2, 3, 3, 4, 4, 3, 3, 2, 2, 1, 1, 0, 0)
 TAP_NAMES = tuple(
     f"{p}.double_conv.{c}"
@@ -104,26 +109,27 @@ def _double_conv(cin: int, cout: int, mid: int | None = None) -> _Holder:
 
 
 class UNet(_Holder):
-    """Parameter tree of the reference UNet (unet.py:65-82); widths 64-128-256-512-512."""
+    """Parameter tree of the reference UNet (unet.py:65-82); widths 64-128-256-512-512 with the bilinear
+    decoder (every reference caller), 64-128-256-512-1024 with the ConvTranspose2d decoder (the default)."""
 
     def __init__(self, n_channels: int = 2, n_classes: int = 1, bilinear: bool = False):
         super().__init__()
         self.n_channels = n_channels
         self.n_classes = n_classes
         self.bilinear = bilinear
-        if not bilinear:
-            raise NotImplementedError(
-                "bilinear=False (ConvTranspose2d decoder, unet.py:42-44) is not built for the "
-                "MI355X path; every reference caller constructs bilinear=True (inference.py:77)")
         self.inc = _double_conv(n_channels, 64)
-        for name, cin, cout in _ENCODER:
+        for name, cin, cout in (_ENCODER if bilinear else _ENCODER_CT):
             d = _Holder()
             d.maxpool_conv = _Seq({"0": _Slot("MaxPool2d(2)"), "1": _double_conv(cin, cout)})
             setattr(self, name, d)
-        for name, cin, cout in _DECODER:
+        for name, cin, cout in (_DECODER if bilinear else _DECODER_CT):
             u = _Holder()
-            u.up = _Slot("Upsample(scale_factor=2, mode='bilinear', align_corners=True)")
-            u.conv = _double_conv(cin, cout, cin // 2)
+            if bilinear:
+                u.up = _Slot("Upsample(scale_factor=2, mode='bilinear', align_corners=True)")
+                u.conv = _double_conv(cin, cout, cin // 2)
+            else:   # unet.py:42-44: parameter holder only, the transposed conv runs in convt2x2_kernel
+                u.up = nn.ConvTranspose2d(cin, cin // 2, kernel_size=2, stride=2)
+                u.conv = _double_conv(cin, cout)
             setattr(self, name, u)
         self.outc = _Holder()
         self.outc.conv = nn.Conv2d(64, n_classes, kernel_size=1)
@@ -230,7 +236,7 @@ class FrameInterpolationUNet(nn.Module):
         if self._ctx is None or self._ctx.device_index != idx:
             if self._ctx is not None:
                 self._ctx.close()
-            self._ctx = _native.Context(idx, self.frame_channels, True)
+            self._ctx = _native.Context(idx, self.frame_channels, self.unet.bilinear)
             self._ctx_dirty = True
         fp = self._current_fingerprint()
         if self._ctx_dirty or fp != self._fingerprint:

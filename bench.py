@@ -71,16 +71,21 @@ def conv_flops(h, w):
     return tot + 2.0 * h * w * 64
 
 
-def make_bench_model(precision: str, seed: int = 0, frame_channels: int = 1) -> "P.FrameInterpolationUNet":
+def make_bench_model(precision: str, seed: int = 0, frame_channels: int = 1,
+                     bilinear: bool = True) -> "P.FrameInterpolationUNet":
     """Random-init network of the benchmark: He-scaled conv weights and non-trivial BatchNorm
     statistics so activations stay O(1) through all 19 layers (torch's default init + identity BN
     decays towards zero, and near-zero MFMA operands run at a higher clock than real data: never
     bench on those).  Same weights on every rank."""
     torch.manual_seed(seed)
-    model = P.FrameInterpolationUNet(bilinear=True, precision=precision, frame_channels=frame_channels)
+    model = P.FrameInterpolationUNet(bilinear=bilinear, precision=precision, frame_channels=frame_channels)
     with torch.no_grad():
         for name, prm in model.named_parameters():
-            if prm.dim() == 4 and prm.shape[-1] == 3:
+            if name.endswith(".up.weight"):     # ConvTranspose2d [in, out, 2, 2] (bilinear=False only)
+                prm.normal_(0, (1.0 / prm.shape[0]) ** 0.5)
+            elif name.endswith(".up.bias"):
+                prm.normal_(0, 0.1)
+            elif prm.dim() == 4 and prm.shape[-1] == 3:
                 prm.normal_(0, (2.0 / (prm.shape[1] * 9)) ** 0.5)
             elif prm.dim() == 4:
                 prm.normal_(0, 0.2 / prm.shape[1] ** 0.5)

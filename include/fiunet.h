@@ -31,7 +31,7 @@ enum fiunet_status {
     FIUNET_ERR_NOT_LOADED = 4,    /* forward before load_weights */
     FIUNET_ERR_WORKSPACE = 5,     /* workspace too small */
     FIUNET_ERR_HIP = 6,           /* a HIP runtime call failed; see fiunet_last_error_string */
-    FIUNET_ERR_UNSUPPORTED = 7    /* bilinear=False (ConvTranspose2d variant, unet.py:42-44) */
+    FIUNET_ERR_UNSUPPORTED = 7    /* (reserved; bilinear=False returned this until round 4) */
 };
 
 /* Arithmetic type of the conv path.  FP32: fp32 storage, exact-fp32 MFMA (v_mfma_f32_16x16x4_f32).
@@ -63,7 +63,9 @@ typedef struct fiunet_ctx fiunet_ctx;
 
 /* Replaces FrameInterpolationUNet.__init__ / UNet.__init__ (model/unet.py:99-103, :66-82).
  * frame_channels: 1 = grayscale (the reference's 2->1 network), 3 = RGB (6->3, README variant).
- * bilinear must be 1 (every reference caller passes bilinear=True: model/inference.py:77). */
+ * bilinear: 1 = bilinear-upsample decoder, what every reference caller constructs (model/inference.py:77);
+ * 0 = the constructor's default (model/unet.py:66,99): ConvTranspose2d(C, C/2, 2, 2) decoder (unet.py:42-44), widths
+ * 64-128-256-512-1024, 118-tensor state-dict with `unet.up{k}.up.weight/bias`. */
 int fiunet_create(fiunet_ctx** out_ctx, int device_id, int frame_channels, int bilinear);
 
 /* Replaces nn.Module teardown (Python GC). */

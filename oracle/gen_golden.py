@@ -82,6 +82,39 @@ SSIM_CASES = (  # name, seed, B, C, H, W, value range, noise
 )
 
 
+def gen_convt():
+    """The constructor's DEFAULT variant, bilinear=False (unet.py:42-44,66,99): ConvTranspose2d(k=2, s=2) decoder,
+    31 037 057 parameters.  No reference caller constructs it (inference.py:77 passes bilinear=True), but it is what
+    `FrameInterpolationUNet()` builds.  Fixtures: the 118-tensor state-dict schema and whole-net outputs of the REAL
+    class with the seeded checkpoint of make_seeded_state_dict(bilinear=False), incl. odd sizes (F.pad after the
+    transposed conv) and one per-block set of activations."""
+    sys.path.insert(0, REF_DIR)
+    from unet import FrameInterpolationUNet
+    torch.manual_seed(0)
+    torch.set_num_threads(8)
+    sd = O.make_seeded_state_dict(WEIGHT_SEED, bilinear=False)
+    model = FrameInterpolationUNet()          # the default constructor
+    assert model.unet.bilinear is False
+    print("load_state_dict:", model.load_state_dict(sd, strict=True))
+    model.eval()
+    schema = [(k, tuple(v.shape), str(v.dtype)) for k, v in model.state_dict().items()]
+    assert [(k, s) for k, s, _ in schema] == [(k, tuple(s)) for k, s, _ in O.state_dict_schema(bilinear=False)]
+    with open(os.path.join(GOLD, "state_dict_schema_convt.txt"), "w") as f:
+        for k, shp, dt in schema:
+            f.write(f"{k}\t{','.join(map(str, shp))}\t{dt}\n")
+    print("params:", sum(p.numel() for p in model.parameters()))
+    for name, seed, b, h, w in (("b1_32x48", 21, 1, 32, 48), ("b2_17x31", 22, 2, 17, 31), ("b1_135x240", 23, 1, 135, 240),
+                                ("b1_70x86", 24, 1, 70, 86)):
+        f1, f2 = O.make_frames(seed, b, h, w)
+        with torch.no_grad():
+            out = model(f1, f2)
+        mine = O.unet_forward(sd, f1, f2)
+        print(f"convt {name}: out std {out.std():.4f} min {out.min():.3f} max {out.max():.3f} "
+              f"|restatement-ref| {float((mine - out).abs().max()):.3e}")
+        np.savez_compressed(os.path.join(GOLD, f"out_convt_{name}.npz"), seed=seed, weight_seed=WEIGHT_SEED,
+                            frame1=f1.numpy(), frame2=f2.numpy(), out=out.numpy())
+
+
 def make_ssim_pair(seed, b, c, h, w, rng_kind, noise):
     """Smooth structure + noise (so the variance terms are neither 0 nor dominated by noise)."""
     g = torch.Generator().manual_seed(seed)
@@ -137,6 +170,9 @@ def main():
     if "--ssim-only" in sys.argv:
         os.makedirs(GOLD, exist_ok=True)
         return gen_ssim()
+    if "--convt-only" in sys.argv:  # add the bilinear=False fixtures without re-recording the others
+        os.makedirs(GOLD, exist_ok=True)
+        return gen_convt()
     if "--rgb-only" in sys.argv:  # add the RGB fixtures without re-recording the others
         os.makedirs(GOLD, exist_ok=True)
         return gen_rgb()

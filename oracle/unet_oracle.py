@@ -32,11 +32,25 @@ import torch.nn.functional as F
 
 BN_EPS = 1e-5  # nn.BatchNorm2d default (unet.py:13,16)
 
-# (state-dict prefix, in_channels, mid_channels, out_channels) for the bilinear=True variant
-# (the only one any reference caller constructs: inference.py:77).  `cin0` is n_channels.
+# (state-dict prefix, in_channels, mid_channels, out_channels).  bilinear=True is the only variant any
+# reference caller constructs (inference.py:77): factor 2, Up's DoubleConv has mid = in // 2 (unet.py:41,77-81).
+# bilinear=False is the constructor's DEFAULT (unet.py:66,99): factor 1, down4 goes to 1024 channels, Up is
+# ConvTranspose2d(in, in // 2, 2, 2) + DoubleConv(in, out) with mid = out (unet.py:42-44).  `cin0` is n_channels.
 
 
-def double_conv_table(n_channels: int = 2):
+def double_conv_table(n_channels: int = 2, bilinear: bool = True):
+    if not bilinear:
+        return [
+            ("unet.inc", n_channels, 64, 64),
+            ("unet.down1.maxpool_conv.1", 64, 128, 128),
+            ("unet.down2.maxpool_conv.1", 128, 256, 256),
+            ("unet.down3.maxpool_conv.1", 256, 512, 512),
+            ("unet.down4.maxpool_conv.1", 512, 1024, 1024),
+            ("unet.up1.conv", 1024, 512, 512),
+            ("unet.up2.conv", 512, 256, 256),
+            ("unet.up3.conv", 256, 128, 128),
+            ("unet.up4.conv", 128, 64, 64),
+        ]
     return [
         ("unet.inc", n_channels, 64, 64),
         ("unet.down1.maxpool_conv.1", 64, 128, 128),
@@ -50,10 +64,15 @@ def double_conv_table(n_channels: int = 2):
     ]
 
 
-def state_dict_schema(n_channels: int = 2, n_classes: int = 1):
-    """Ordered (name, shape, dtype) list of the reference state-dict (110 tensors)."""
+def state_dict_schema(n_channels: int = 2, n_classes: int = 1, bilinear: bool = True):
+    """Ordered (name, shape, dtype) list of the reference state-dict (110 tensors; bilinear=False:
+    118 - every Up block's ConvTranspose2d `up.weight [in, in // 2, 2, 2]`, `up.bias [in // 2]` come first)."""
     out = []
-    for prefix, cin, mid, cout in double_conv_table(n_channels):
+    for prefix, cin, mid, cout in double_conv_table(n_channels, bilinear):
+        if not bilinear and prefix.startswith("unet.up"):
+            blk = prefix[:-len(".conv")]
+            out.append((f"{blk}.up.weight", (cin, cin // 2, 2, 2), torch.float32))
+            out.append((f"{blk}.up.bias", (cin // 2,), torch.float32))
         for conv_i, bn_i, ci, co in ((0, 1, cin, mid), (3, 4, mid, cout)):
             out.append((f"{prefix}.double_conv.{conv_i}.weight", (co, ci, 3, 3), torch.float32))
             out.append((f"{prefix}.double_conv.{bn_i}.weight", (co,), torch.float32))
@@ -66,16 +85,20 @@ def state_dict_schema(n_channels: int = 2, n_classes: int = 1):
     return out
 
 
-def make_seeded_state_dict(seed: int = 1234, n_channels: int = 2, n_classes: int = 1):
+def make_seeded_state_dict(seed: int = 1234, n_channels: int = 2, n_classes: int = 1, bilinear: bool = True):
     """Deterministic non-trivial checkpoint: He-scaled conv weights, randomised BN affine and
     running statistics (a fresh model has identity BN and ~constant output, which would make an
     absolute-tolerance parity test vacuous -- SURVEY section 7 'Fixture design').  Only plain
     torch CPU RNG calls, so the same tensors can be rebuilt anywhere from the seed."""
     g = torch.Generator().manual_seed(seed)
     sd = OrderedDict()
-    for name, shape, dtype in state_dict_schema(n_channels, n_classes):
+    for name, shape, dtype in state_dict_schema(n_channels, n_classes, bilinear):
         if dtype == torch.int64:
             sd[name] = torch.tensor(7, dtype=torch.int64)
+        elif name.endswith(".up.weight"):   # ConvTranspose2d [in, out, 2, 2]: every output is a sum over `in` terms
+            sd[name] = torch.randn(shape, generator=g) * math.sqrt(1.0 / shape[0])
+        elif name.endswith(".up.bias"):
+            sd[name] = torch.randn(shape, generator=g) * 0.1
         elif name.endswith("conv.weight") and len(shape) == 4 and shape[2] == 1:
             sd[name] = torch.randn(shape, generator=g) * (0.2 / math.sqrt(shape[1]))
         elif len(shape) == 4:
@@ -180,9 +203,13 @@ def _double_conv(x, sd, prefix, taps):
     return x
 
 
-def upsample_pad_concat(x_low, x_skip):
-    """unet.py:46-54 -- bilinear x2 (align_corners=True), asymmetric zero pad, cat([skip, up])."""
-    up = F.interpolate(x_low, scale_factor=2, mode="bilinear", align_corners=True)
+def upsample_pad_concat(x_low, x_skip, up_weight=None, up_bias=None):
+    """unet.py:46-54 -- bilinear x2 (align_corners=True), or ConvTranspose2d(k=2, s=2) when the checkpoint has
+    one (bilinear=False, unet.py:42-44); asymmetric zero pad, cat([skip, up])."""
+    if up_weight is not None:
+        up = F.conv_transpose2d(x_low, up_weight, up_bias, stride=2)
+    else:
+        up = F.interpolate(x_low, scale_factor=2, mode="bilinear", align_corners=True)
     dy = x_skip.shape[2] - up.shape[2]
     dx = x_skip.shape[3] - up.shape[3]
     up = F.pad(up, [dx // 2, dx - dx // 2, dy // 2, dy - dy // 2])
@@ -203,7 +230,7 @@ def unet_forward(sd, frame1, frame2, taps=None):
         cur = _double_conv(cur, sd, f"unet.down{k}.maxpool_conv.1", taps)
         skips.append(cur)
     for k, skip in zip((1, 2, 3, 4), (skips[3], skips[2], skips[1], skips[0])):
-        cat = upsample_pad_concat(cur, skip)
+        cat = upsample_pad_concat(cur, skip, sd.get(f"unet.up{k}.up.weight"), sd.get(f"unet.up{k}.up.bias"))
         if taps is not None:
             taps[f"unet.up{k}.cat"] = cat
         cur = _double_conv(cat, sd, f"unet.up{k}.conv", taps)

@@ -42,6 +42,7 @@ def test_argument_validation_without_gpu(hip_lib_built):
     h = ctypes.c_void_p()
     assert lib.fiunet_create(ctypes.byref(h), 0, 2, 1) == 1  # frame_channels must be 1 or 3
     assert b"frame_channels" in lib.fiunet_last_error_string()
-    assert lib.fiunet_create(ctypes.byref(h), 0, 1, 0) == 7  # bilinear=False unsupported
+    # bilinear=False (round 4: built) gets past the argument checks and fails on the device query here (no GPU)
+    assert lib.fiunet_create(ctypes.byref(h), 0, 1, 0) != 7
     assert lib.fiunet_workspace_bytes(None, 1, 64, 64, 0) == 0
     assert lib.fiunet_preprocess_u8(None, None, 4, None) == 1

@@ -29,10 +29,22 @@ def test_rgb_variant_schema():
     assert tuple(sd["unet.outc.conv.weight"].shape) == (3, 64, 1, 1)
 
 
-def test_constructor_default_is_bilinear_false_and_unsupported():
-    # reference default is bilinear=False (unet.py:99); that decoder is out of scope and says so
-    with pytest.raises(NotImplementedError):
-        P.FrameInterpolationUNet()
+def test_constructor_default_is_the_convtranspose_variant(golden_dir):
+    """The reference's default is bilinear=False (unet.py:99 -> :66): ConvTranspose2d decoder, 31 037 057 parameters
+    (QUICK_START.md's "31,031,809" matches neither variant).  Same 118-tensor state-dict - names,
+    shapes, order - as the real class (fixture dumped from it by oracle/gen_golden.py --convt-only), strict load of
+    the seeded checkpoint, and the attribute tree the reference exposes (`up1.up` is the transposed conv)."""
+    m = P.FrameInterpolationUNet()
+    assert m.unet.bilinear is False and P.count_parameters(m) == 31037057
+    want = [l.rstrip("\n").split("\t") for l in open(os.path.join(golden_dir, "state_dict_schema_convt.txt"))]
+    got = [(k, ",".join(map(str, v.shape)), str(v.dtype)) for k, v in m.state_dict().items()]
+    assert got == [tuple(w) for w in want]
+    res = m.load_state_dict(O.make_seeded_state_dict(1234, bilinear=False), strict=True)
+    assert not res.missing_keys and not res.unexpected_keys
+    assert tuple(m.unet.up1.up.weight.shape) == (1024, 512, 2, 2) and tuple(m.unet.up4.up.bias.shape) == (64,)
+    assert tuple(m.unet.down4.maxpool_conv[1].double_conv[3].weight.shape) == (1024, 1024, 3, 3)
+    with pytest.raises(Exception):   # a bilinear=True checkpoint does not fit (different widths, no `up` tensors)
+        m.load_state_dict(O.make_seeded_state_dict(1234), strict=True)
 
 
 def test_load_state_dict_strict_roundtrip(seeded_sd):

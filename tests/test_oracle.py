@@ -115,3 +115,19 @@ def test_interpolating_checkpoint_interpolates():
     f1, f2 = O.make_frames(5, 1, 32, 48, c=3)
     out3 = O.unet_forward(sd3, f1, f2)
     assert float((out3 - 0.5 * (f1 + f2)).pow(2).mean().sqrt()) <= 0.08
+
+
+CONVT_GOLD = ["b1_32x48", "b2_17x31", "b1_135x240", "b1_70x86"]
+
+
+@pytest.mark.parametrize("name", CONVT_GOLD)
+def test_convtranspose_variant_oracle_equals_reference_default_constructor(golden_dir, name):
+    """bilinear=False - what `FrameInterpolationUNet()` builds (unet.py:99 -> :66, Up's ConvTranspose2d branch :42-44)
+    - is pinned to outputs of the reference's own class with the seeded 118-tensor checkpoint (oracle/gen_golden.py
+    gen_convt), incl. odd sizes (F.pad after the transposed conv)."""
+    g = np.load(os.path.join(golden_dir, f"out_convt_{name}.npz"))
+    sd = O.make_seeded_state_dict(int(g["weight_seed"]), bilinear=False)
+    assert len(sd) == 118 and tuple(sd["unet.up1.up.weight"].shape) == (1024, 512, 2, 2)
+    out = O.unet_forward(sd, torch.from_numpy(g["frame1"]), torch.from_numpy(g["frame2"])).numpy()
+    assert out.shape == g["out"].shape
+    assert np.abs(out - g["out"]).max() <= 2e-5 * max(1.0, np.abs(g["out"]).max())
