@@ -503,7 +503,7 @@ int forward_impl(fiunet_ctx* ctx, const float* f1, const float* f2, float* out, 
                 const long long ntiles = (long long)B * ((H + 15) / 16) * ((W + 31) / 32);
                 dim3 g2((unsigned)std::min<long long>(ntiles, 256 * 4));
                 hipLaunchKernelGGL(stem_rgb_split_kernel, g2, dim3(256), 0, s, f1, f2, (const float*)cw.w_f32, cw.scale,
-                                   cw.shift, (__bf16*)act(0), B, H, W, stem_dither_amp);
+                                   cw.shift, (__bf16*)act(0), B, H, W, stem_dither_amp, u1, u2);
                 stem_split_rgb = true;
             }
         } else
@@ -897,12 +897,13 @@ int fiunet_forward_strip(fiunet_ctx* ctx, const float* frame1, const float* fram
 }
 
 // fiunet_forward_u8: which of the three fp32 frame buffers (frame1, frame2, output logits) a forward of
-// this shape still needs - none where the stem reads the uint8 frames itself (fused stem: bf16 gray) and the
+// this shape still needs - none where the stem reads the uint8 frames itself (fused stem: bf16 gray; split stem: bf16 RGB) and the
 // fused head writes uint8 itself (every fused-head forward).
 static void u8_buffers(const fiunet_ctx* ctx, int H, int W, int precision, bool* in_f32, bool* out_f32)
 {
     const PlanOpts po = plan_opts(ctx, H, W, precision);
-    *in_f32 = !po.fused_stem;
+    // the bf16 RGB stem (stem_rgb_split_kernel) reads the uint8 frames itself too
+    *in_f32 = !(po.fused_stem || (precision == FIUNET_BF16 && ctx->cf == 3));
     *out_f32 = !po.fused_head;
 }
 

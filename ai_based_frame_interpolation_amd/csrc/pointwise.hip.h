@@ -145,8 +145,10 @@ __global__ __launch_bounds__(256) void conv3x3_first_kernel(
 __global__ __launch_bounds__(256) void stem_rgb_split_kernel(
     const float* __restrict__ f1, const float* __restrict__ f2, const float* __restrict__ w,  // w: [9 taps][6][64] fp32
     const float* __restrict__ scale, const float* __restrict__ shift, __bf16* __restrict__ dst, int B, int H, int W,
-    float dither)
+    float dither, const uint8_t* __restrict__ u1, const uint8_t* __restrict__ u2)
 {
+    // u1 / u2 != nullptr (fiunet_forward_u8): the uint8 frames [B][3][H][W] are read and normalised right here
+    // (preprocess_u8_value: the same fp32 values fiunet_preprocess_u8 would have written), f1 / f2 are unused
     constexpr int CF = 3, TH = 16, TW = 32, PH = TH + 2, PW = TW + 4;
     constexpr int IMG = PH * PW;                 // dwords of one (colour, hi | lo) patch image
     constexpr int BIAS_OFF = 6 * IMG;            // 8 dwords {1.0, 0}, 0, 0, ... (hi operand of the bias k-group)
@@ -207,7 +209,10 @@ __global__ __launch_bounds__(256) void stem_rgb_split_kernel(
             const float d = dither * stem_dither(y, x);
 #pragma unroll
             for (int c = 0; c < CF; ++c) {
-                float v0 = f1[((size_t)b * CF + c) * plane + at], v1 = f2[((size_t)b * CF + c) * plane + at];
+                const size_t idx = ((size_t)b * CF + c) * plane + at;
+                float v0, v1;
+                if (u1) { v0 = preprocess_u8_value(u1[idx]); v1 = preprocess_u8_value(u2[idx]); }   // wave-uniform
+                else { v0 = f1[idx]; v1 = f2[idx]; }
                 v0 = ok ? v0 + d : 0.f;   // +d on frame 1, -d on frame 2; the conv's zero padding stays exactly zero
                 v1 = ok ? v1 - d : 0.f;
                 const unsigned hi = pack_bf16x2_pk(v0, v1);

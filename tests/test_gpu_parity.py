@@ -344,7 +344,7 @@ def test_random_shapes_fp32_and_bf16_vs_oracle(model, dev, seeded_sd):
 def test_u8_read_and_write_fused_into_stem_and_head_bitwise(dev, prec, cf, h, w, unfused):
     """fiunet_forward_u8 == fiunet_preprocess_u8 -> fiunet_forward -> fiunet_postprocess_u8 bit for bit
     (inference.py:31-35, :54-61), whether the uint8 frames are read by the fused stem / written by the fused
-    head (bf16 gray: no fp32 frame buffer at all; fp32 and RGB: fused head only) or go through the two
+    head (bf16 gray and, round 4, bf16 RGB: no fp32 frame buffer at all; fp32: fused head only) or go through the two
     elementwise kernels (ablation path, narrow frames), and the workspace query shrinks accordingly."""
     from ai_based_frame_interpolation_amd import _native
     sd = O.make_seeded_state_dict(77 if cf == 3 else 1234, n_channels=2 * cf, n_classes=cf)
@@ -363,7 +363,8 @@ def test_u8_read_and_write_fused_into_stem_and_head_bitwise(dev, prec, cf, h, w,
     base, u8b = ctx.workspace_bytes(2, h, w, pcode), ctx.workspace_bytes(2, h, w, pcode, u8=True)
     frame = -(-2 * cf * h * w * 4 // 256) * 256
     fused_stem = prec == "bf16" and cf == 1 and not unfused and w >= 32  # 16x32 tiles preferred
-    nbuf = (0 if fused_stem else 2) + (1 if unfused else 0)
+    stem_reads_u8 = fused_stem or (prec == "bf16" and cf == 3)           # round 4: the split-bf16 RGB stem does too
+    nbuf = (0 if stem_reads_u8 else 2) + (1 if unfused else 0)
     assert u8b - base == nbuf * frame, (u8b - base, nbuf, frame)
 
 
