@@ -21,7 +21,7 @@ _PKG = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("FIUNET_LIB") or os.path.join(_PKG, "libfiunet_hip.so")  # FIUNET_LIB: A/B builds
 CSRC = os.path.join(_PKG, "csrc")
 
-FP32, BF16 = 0, 1
+FP32, BF16, BF16X2 = 0, 1, 2   # include/fiunet.h: enum fiunet_precision
 OPT_UNFUSED, OPT_KEEP_ALL, OPT_PAIR_TILES, OPT_GATHER_UPSAMPLE = 1, 2, 8, 16
 OPT_RNE_WEIGHTS, OPT_NO_DITHER = 32, 64
 

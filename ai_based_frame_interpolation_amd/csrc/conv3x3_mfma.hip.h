@@ -425,7 +425,13 @@ __device__ __forceinline__ void mma_chunk<float>(f32x4& acc, const uint4& wa, co
 }
 
 enum Epilogue { EPI_PLAIN = 0, EPI_HEAD = 1 /* 1x1 head, 1 class */, EPI_POOL = 2, EPI_HEAD3 = 3 /* 3 classes */,
-                EPI_SPLITK = 4 /* raw fp32 partial sums of a K slice -> slab (small problems) */ };
+                EPI_SPLITK = 4 /* raw fp32 partial sums of a K slice -> slab (small problems) */,
+                // "bf16x2" precision (fp32 contract on the bf16 pipe): every activation is stored as TWO bf16 pieces,
+                // x = hi + lo (16 significant bits), in a tensor of 3 * C channels laid out [hi | hi | lo]; with the
+                // weights packed [wh | wl | wh] a plain bf16 conv over those 3 * C channels computes
+                // wh*xh + wl*xh + wh*xl (the dropped wl*xl term is 2^-16 relative) - the K loop and the gathers are
+                // the bf16 kernel's, unchanged; only the epilogue differs: it splits relu(acc) and writes the three blocks.
+                EPI_PLAIN_X2 = 5, EPI_POOL_X2 = 6 };
 
 // value of the neighbouring lane (lane ^ 1) through DPP quad_perm [1,0,3,2]: no LDS crossbar
 __device__ __forceinline__ unsigned dpp_swap_pairs(unsigned v)
@@ -569,6 +575,73 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x4 (&acc)[4]
                 for (int m = 0; m < 4; ++m)
                     *reinterpret_cast<float4*>(o + conv_cout_ofs<T>(m, lc)) =
                         make_float4(acc[m][n][0], acc[m][n][1], acc[m][n][2], acc[m][n][3]);
+            }
+        }
+        return;
+    }
+    if constexpr (EPI == EPI_PLAIN_X2 || EPI == EPI_POOL_X2) {
+        static_assert(sizeof(T) == 2, "the two-piece epilogue belongs to the bf16 kernels");
+        const size_t ps = (size_t)aH * aW * 64;                  // bytes of one 32-channel plane
+        const int npo = a.Cout / 32;                             // planes per block; the tensor has 3 * npo
+        const size_t blk = (size_t)npo * ps;                     // bytes from one block to the next
+        char* const img = (char*)a.dst + (size_t)b * 3 * blk + (size_t)(wbase_c / 32) * ps + lc * 16;
+        const int pH2 = aH >> 1, pW2 = aW >> 1;
+        const size_t pps = (size_t)pH2 * pW2 * 64, pblk = (size_t)npo * pps;
+        char* const pimg = EPI == EPI_POOL_X2 ? (char*)a.pool_dst + (size_t)b * 3 * pblk + (size_t)(wbase_c / 32) * pps + lc * 16
+                                              : nullptr;
+        // 8 consecutive couts of this lane (accumulator tiles 2g, 2g + 1) -> hi and lo chunk, three stores
+        auto put = [&](char* o, size_t block_bytes, const float (&v)[8]) __attribute__((always_inline)) {
+            unsigned h[4], l[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                h[i] = pack_bf16x2_pk(v[2 * i], v[2 * i + 1]);
+                l[i] = pack_bf16x2_pk(v[2 * i] - __uint_as_float(h[i] << 16), v[2 * i + 1] - __uint_as_float(h[i] & 0xffff0000u));
+            }
+            const uint4 hv = make_uint4(h[0], h[1], h[2], h[3]);
+            *reinterpret_cast<uint4*>(o) = hv;
+            *reinterpret_cast<uint4*>(o + block_bytes) = hv;
+            *reinterpret_cast<uint4*>(o + 2 * block_bytes) = make_uint4(l[0], l[1], l[2], l[3]);
+        };
+#pragma unroll
+        for (int n = 0; n < NF; ++n) {
+            const int y = y0 + wp * ROWS_W + n / FR;
+            const int x = x0 + (n % FR) * 16 + l15;
+            if (y < aH && x < aW) {
+#pragma unroll
+                for (int g = 0; g < 2; ++g) {
+                    float v[8];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        v[j] = a.relu ? fmaxf(acc[2 * g][n][j], 0.f) : acc[2 * g][n][j];
+                        v[4 + j] = a.relu ? fmaxf(acc[2 * g + 1][n][j], 0.f) : acc[2 * g + 1][n][j];
+                    }
+                    put(img + (size_t)(y * aW + x) * 64 + g * ps, blk, v);
+                }
+            }
+        }
+        if constexpr (EPI == EPI_POOL_X2) {
+            // MaxPool2d(2) on the fp32 values (relu is monotonic): rows n / n + FR of this wave, column partner = lane ^ 1
+#pragma unroll
+            for (int n = 0; n < NF; ++n) {
+                if (((n / FR) & 1) != 0) continue;
+                const int y = y0 + wp * ROWS_W + n / FR;
+                const int x = x0 + (n % FR) * 16 + l15;
+                const int py = y >> 1, px = x >> 1;
+                const bool okp = (py < pH2) && (px < pW2) && ((l15 & 1) == 0);
+#pragma unroll
+                for (int g = 0; g < 2; ++g) {
+                    float v[8];
+#pragma unroll
+                    for (int h = 0; h < 2; ++h)
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            const float cm = fmaxf(acc[2 * g + h][n][j], acc[2 * g + h][n + FR][j]);
+                            float r = fmaxf(cm, __uint_as_float(dpp_swap_pairs(__float_as_uint(cm))));
+                            if (a.relu) r = fmaxf(r, 0.f);
+                            v[4 * h + j] = r;
+                        }
+                    if (okp) put(pimg + (size_t)(min(py, pH2 - 1) * pW2 + min(px, pW2 - 1)) * 64 + g * pps, pblk, v);
+                }
             }
         }
         return;
@@ -869,7 +942,7 @@ __global__ __launch_bounds__(256, conv_occupancy(BN, TH, TW)) void conv3x3_mfma_
     // and a plane's gather costs ~8 instructions per piece; the pooled / concat / head / split-K
     // variants and the 64-cout tiles (12-14 pieces per wave), which are at the 256-VGPR limit,
     // rebuild it per plane from three registers (see pm_* below; hoisting there spills).
-    constexpr bool HOIST = (MODE == SRC_DIRECT && BN == 128 && EPI == EPI_PLAIN);
+    constexpr bool HOIST = (MODE == SRC_DIRECT && BN == 128 && EPI == EPI_PLAIN);   // (EPI_PLAIN_X2 with it: 3 spilled registers)
     // Rolling window of in-tile rows across the three ky taps of a step (24 instead of 36 fragment
     // reads per step): bf16 32-wide tiles.  The fp32 instantiations (4 MFMAs per fragment pair keep
     // more operands in flight) and the 16-wide tiles have no registers to spare for the extra row

@@ -71,6 +71,7 @@ struct ConvWeights {
     int cin = 0, cout = 0;
     void* w_f32 = nullptr;   // packed [cin/16][kx][ky][cout][16] fp32   (conv 0: [9][cin][64])
     void* w_bf16 = nullptr;  // packed [cin/32][kx][ky][cout][32] bf16
+    void* w_x2 = nullptr;    // FIUNET_BF16X2: the same packing over 3 * cin input channels, pieces [wh | wl | wh]
     float* scale = nullptr;
     float* shift = nullptr;
 };
@@ -130,6 +131,7 @@ struct Plan {
     size_t scratch_off;
     size_t up_off[NCONV];  // upsampled half of a concat input, where it is materialised (else unused)
     size_t slab_off;   // split-K partial sums (small problems), kSlabBytes
+    size_t stem32_off; // FIUNET_BF16X2: the exact-fp32 stem's output before it is split into pieces
     size_t total;
 };
 
@@ -145,6 +147,7 @@ struct PlanOpts {
     bool keep_all = false, unfused = false, fused_stem = false, fused_head = false, gather_up = false;
     const int* cout = kCoutBil;   // architecture: output channels per conv
     bool convt = false;           // bilinear=False: the upsampled half is a ConvTranspose2d output, always materialised
+    bool x2 = false;              // FIUNET_BF16X2: activations are [hi | hi | lo] bf16 tensors of 3 * C channels
 };
 
 // A concat conv whose output spans several 128-cout tiles would bilinearly interpolate every input
@@ -155,7 +158,7 @@ struct PlanOpts {
 inline bool materialise_up(int stage, int precision, bool unfused, long long pixels, const int* cout = kCoutBil,
                            bool convt = false)
 {
-    if (convt) return kMode[stage] == SRC_CONCAT_UP;   // there is no "interpolate in the gather" for a transposed conv
+    if (convt || precision == FIUNET_BF16X2) return kMode[stage] == SRC_CONCAT_UP;   // (no in-gather form for these)
     return precision == FIUNET_BF16 && !unfused && kMode[stage] == SRC_CONCAT_UP && cout[stage] >= 256 &&
            pixels >= 65536;
 }
@@ -166,7 +169,7 @@ bool make_plan(int B, int H, int W, int precision, const PlanOpts& o, Plan& p)
     // the kernels address a pixel record inside one image plane with 32 bits: H*W*64 B < 4 GiB.
     // Larger frames go through fiunet_forward_strip band by band.
     if ((long long)H * W >= (1LL << 26)) return false;
-    const size_t es = precision == FIUNET_BF16 ? 2 : 4;
+    const size_t es = precision == FIUNET_FP32 ? 4 : (o.x2 ? 6 : 2);   // bytes per activation element
     p.hs[0] = H; p.ws[0] = W;
     for (int k = 1; k < 5; ++k) { p.hs[k] = p.hs[k - 1] / 2; p.ws[k] = p.ws[k - 1] / 2; }
     struct Buf { size_t bytes; int first, last; size_t* off; };
@@ -194,6 +197,8 @@ bool make_plan(int B, int H, int W, int precision, const PlanOpts& o, Plan& p)
                                      (o.convt ? o.cout[kSrc1[i]] / 2 : o.cout[kSrc1[i]]) * es), i,
                             o.keep_all ? END : i, &p.up_off[i]});
     }
+    p.stem32_off = 0;
+    if (o.x2) bufs.push_back({align256((size_t)B * H * W * 64 * 4), 0, 1, &p.stem32_off});
     p.scratch_off = 0;
     if (o.unfused && !o.convt)  // ablation path: concat tensor (<= 128 ch at level 0), rewritten by every Up block
         bufs.push_back({align256((size_t)B * H * W * 128 * es), 0, END, &p.scratch_off});
@@ -410,6 +415,8 @@ PlanOpts plan_opts(const fiunet_ctx* ctx, int H, int W, int precision)
     o.fused_head = !o.unfused && !o.keep_all;  // OutConv reduced in the last conv's epilogue
     o.cout = ctx->cout;
     o.convt = !ctx->bilinear;
+    o.x2 = precision == FIUNET_BF16X2;
+    if (o.x2) { o.fused_stem = false; o.fused_head = true; o.keep_all = o.unfused = o.gather_up = false; }
     return o;
 }
 
@@ -439,6 +446,10 @@ template <typename T> int launch_conv(const ConvArgs& a, int mode, int epi, hipS
     if (mode == SRC_DIRECT && epi == EPI_HEAD) return launch_conv_shape<T, SRC_DIRECT, EPI_HEAD>(a, s);
     if (mode == SRC_DIRECT && epi == EPI_HEAD3) return launch_conv_shape<T, SRC_DIRECT, EPI_HEAD3>(a, s);
     if (mode == SRC_DIRECT && epi == EPI_POOL) return launch_conv_shape<T, SRC_DIRECT, EPI_POOL>(a, s);
+    if constexpr (sizeof(T) == 2) {   // FIUNET_BF16X2: splitting epilogues
+        if (mode == SRC_DIRECT && epi == EPI_PLAIN_X2) return launch_conv_shape<T, SRC_DIRECT, EPI_PLAIN_X2>(a, s);
+        if (mode == SRC_DIRECT && epi == EPI_POOL_X2) return launch_conv_shape<T, SRC_DIRECT, EPI_POOL_X2>(a, s);
+    }
     if constexpr (sizeof(T) == 2) {
         if (mode == SRC_STEM && epi == EPI_POOL && a.Cout == 64)  // 16x32 tiles only (LDS budget)
             return launch_conv_cfg<T, 64, 16, 32, SRC_STEM, EPI_POOL>(a, s);
@@ -642,6 +653,111 @@ int forward_impl(fiunet_ctx* ctx, const float* f1, const float* f2, float* out, 
     return FIUNET_OK;
 }
 
+// FIUNET_BF16X2: the fp32 contract on the bf16 pipe (include/fiunet.h).  Activations are two-piece tensors of 3 * C bf16
+// channels [hi | hi | lo]; every conv is the plain bf16 direct kernel over them with the [wh | wl | wh] weights and a
+// splitting epilogue (EPI_PLAIN_X2 / EPI_POOL_X2), the stem is the exact-fp32 kernel followed by a split pass, the
+// upsampled halves are always materialised (x2_upsample_kernel: fp32 interpolation of hi + lo), the head is the usual
+// fused fp32 reduction.  No K-split (small frames run the un-split kernels), no ablation / read-back options.
+int forward_x2(fiunet_ctx* ctx, const float* f1, const float* f2, float* out, int B, int H, int W, char* ws,
+               const Plan& p, hipStream_t s, int y_origin, int Hg, uint8_t* out_u8)
+{
+    using T = __bf16;
+    if (!ctx->bilinear) return fail(FIUNET_ERR_UNSUPPORTED, "bf16x2: bilinear=True only");
+    int hg[5];
+    hg[0] = Hg;
+    for (int l = 1; l < 5; ++l) hg[l] = hg[l - 1] / 2;
+    auto act = [&](int i) { return ws + p.act_off[i]; };
+    hipEvent_t* ev = nullptr;
+    if (ctx->profiling) {
+        if (ctx->ev_used + NCONV + 1 > ctx->ev_pool.size()) {
+            const size_t old = ctx->ev_pool.size();
+            ctx->ev_pool.resize(old + 64 * (NCONV + 1));
+            for (size_t k = old; k < ctx->ev_pool.size(); ++k) HIP_TRY(hipEventCreate(&ctx->ev_pool[k]));
+        }
+        ev = ctx->ev_pool.data() + ctx->ev_used;
+        ctx->ev_used += NCONV + 1;
+        HIP_TRY(hipEventRecord(ev[0], s));
+    }
+    {   // conv 0: exact-fp32 stem (no dither: this is the fp32-contract path), then the split into pieces
+        const ConvWeights& cw = ctx->conv[0];
+        float* stem32 = (float*)(ws + p.stem32_off);
+        const long long nruns = (long long)B * H * (((W + 15) / 16 + 7) / 8);
+        dim3 grid((unsigned)std::min<long long>((nruns + 3) / 4, 256 * 64));
+        if (ctx->cf == 1)
+            hipLaunchKernelGGL((conv3x3_first_kernel<float, 1>), grid, dim3(256), 0, s, f1, f2, (const float*)cw.w_f32,
+                               cw.scale, cw.shift, stem32, B, H, W, 0.f);
+        else
+            hipLaunchKernelGGL((conv3x3_first_kernel<float, 3>), grid, dim3(256), 0, s, f1, f2, (const float*)cw.w_f32,
+                               cw.scale, cw.shift, stem32, B, H, W, 0.f);
+        HIP_TRY(hipGetLastError());
+        const size_t n = (size_t)B * 2 * H * W * 4;
+        hipLaunchKernelGGL(x2_split_kernel, dim3(grid_for(n)), dim3(256), 0, s, stem32, act(0), B, H * W, 64);
+        HIP_TRY(hipGetLastError());
+        if (ev) {
+            HIP_TRY(hipEventRecord(ev[1], s));
+            ctx->layer_name[0] = "conv3x3_first_kernel<f32> + x2_split_kernel";
+            ctx->layer_flops[0] = 2.0 * B * H * W * 9.0 * cw.cin * cw.cout;
+        }
+    }
+    for (int i = 1; i < NCONV; ++i) {
+        const ConvWeights& cw = ctx->conv[i];
+        const int lv = kLevel[i];
+        ConvArgs a;
+        std::memset(&a, 0, sizeof(a));
+        a.B = B; a.H = p.hs[lv]; a.W = p.ws[lv];
+        a.Cout = cw.cout;
+        a.wgt = cw.w_x2;
+        a.scale = cw.scale; a.shift = cw.shift;
+        a.relu = 1;
+        a.zero_page = ctx->zero_page;
+        a.ksplit = 1;
+        a.kslab = nullptr;
+        a.dst = act(i);
+        a.src0 = act(kSrc0[i]);
+        a.C0 = 3 * ctx->cout[kSrc0[i]];
+        if (kMode[i] == SRC_POOL) {
+            a.src0 = ws + p.pool_off[lv - 1];
+        } else if (kMode[i] == SRC_CONCAT_UP) {
+            a.src1 = act(kSrc1[i]);
+            a.C1 = ctx->cout[kSrc1[i]];            // REAL channels for the upsample kernel; tripled below
+            a.lowH = p.hs[lv + 1]; a.lowW = p.ws[lv + 1];
+            a.lowHg = hg[lv + 1];
+            a.upOffY = y_origin >> lv;
+            a.lowOffY = y_origin >> (lv + 1);
+            const int dy = hg[lv] - 2 * a.lowHg, dx = a.W - 2 * a.lowW;
+            a.padT = dy / 2; a.padL = dx / 2;
+            a.sy = 2 * a.lowHg > 1 ? (float)(a.lowHg - 1) / (float)(2 * a.lowHg - 1) : 0.f;
+            a.sx = 2 * a.lowW > 1 ? (float)(a.lowW - 1) / (float)(2 * a.lowW - 1) : 0.f;
+            char* up = ws + p.up_off[i];
+            const size_t n = (size_t)B * (a.C1 / 32) * a.H * a.W * 4;
+            hipLaunchKernelGGL(x2_upsample_kernel, dim3(grid_for(n)), dim3(256), 0, s, a, up);
+            HIP_TRY(hipGetLastError());
+            a.src1 = up;
+            a.C1 = 3 * a.C1;
+        }
+        if (a.C0 + a.C1 != 3 * cw.cin) return fail(FIUNET_ERR_INVALID_ARG, "internal: bf16x2 channel plan mismatch");
+        int epi = EPI_PLAIN_X2;
+        if (kPoolOut[i] >= 0) {
+            epi = EPI_POOL_X2;
+            a.pool_dst = ws + p.pool_off[kPoolOut[i]];
+        }
+        if (i == NCONV - 1) {
+            epi = ctx->cf == 1 ? EPI_HEAD : EPI_HEAD3;
+            a.head_w = ctx->head_w; a.head_b = ctx->head_b; a.head_out = out; a.head_out_u8 = out_u8; a.head_nc = ctx->cf;
+            a.dst = nullptr;
+        }
+        g_name_out = ev ? &ctx->layer_name[i] : nullptr;
+        const int rc = launch_conv<T>(a, SRC_DIRECT, epi, s);
+        g_name_out = nullptr;
+        if (rc != FIUNET_OK) return rc;
+        if (ev) {
+            ctx->layer_flops[i] = 2.0 * B * a.H * a.W * 9.0 * cw.cin * cw.cout;   // algorithmic (the kernel executes 3x)
+            HIP_TRY(hipEventRecord(ev[i + 1], s));
+        }
+    }
+    return FIUNET_OK;
+}
+
 }  // namespace
 
 extern "C" {
@@ -792,6 +908,33 @@ int fiunet_load_weights(fiunet_ctx* ctx, int n, const char* const* names,
         }
         if ((rc = dev_upload(ctx, p32.data(), nel * 4, &cw.w_f32))) return rc;
         if ((rc = dev_upload(ctx, p16.data(), nel * 2, &cw.w_bf16))) return rc;
+        if (ctx->bilinear) {
+            // FIUNET_BF16X2: the same packing over 3 * cin input channels.  The activations arrive as blocks
+            // [hi | hi | lo] per source tensor (a concat conv: the skip tensor's three blocks, then the upsampled
+            // tensor's), the weights go [wh | wl | wh] against them: wh*xh + wl*xh + wh*xl.  w * bn_scale = wh + wl to
+            // 2^-17 relative (both pieces rounded to nearest).
+            const int c0 = kMode[i] == SRC_CONCAT_UP ? kCout[kSrc0[i]] : cin;   // channels of the first source
+            const int cin3 = 3 * cin;
+            std::vector<uint16_t> px((size_t)cout * cin3 * 9);
+            for (int R = 0; R < cout; ++R) {
+                const int co16 = bf16_row_to_cout(R);
+                for (int k = 0; k < cin3; ++k) {
+                    int ci, piece;   // real input channel, weight piece (0 = hi, 1 = lo)
+                    if (k < 3 * c0) { ci = k % c0; piece = (k / c0) == 1; }
+                    else { const int kk = k - 3 * c0, c1 = cin - c0; ci = c0 + kk % c1; piece = (kk / c1) == 1; }
+                    for (int t = 0; t < 9; ++t) {
+                        const int slot = (t % 3) * 3 + t / 3;
+                        const float wv = w[((size_t)co16 * cin + ci) * 9 + t] * sc[co16];
+                        const uint16_t hi = f32_to_bf16_rne(wv);
+                        uint32_t hb = (uint32_t)hi << 16;
+                        float hf;
+                        std::memcpy(&hf, &hb, 4);
+                        px[(((size_t)(k / 32) * 9 + slot) * cout + R) * 32 + (k % 32)] = piece ? f32_to_bf16_rne(wv - hf) : hi;
+                    }
+                }
+            }
+            if ((rc = dev_upload(ctx, px.data(), px.size() * 2, &cw.w_x2))) return rc;
+        }
     }
     if (!ctx->bilinear) {
         // ConvTranspose2d weights [Cin][Cout = Cin / 2][2][2] + bias (unet.py:43): packed per tap t = dy*2 + dx as
@@ -850,7 +993,8 @@ int fiunet_load_weights(fiunet_ctx* ctx, int n, const char* const* names,
 size_t fiunet_workspace_bytes(const fiunet_ctx* ctx, int B, int H, int W, int precision)
 {
     Plan p;
-    if (!ctx || (precision != FIUNET_FP32 && precision != FIUNET_BF16) ||
+    if (!ctx || (precision != FIUNET_FP32 && precision != FIUNET_BF16 && precision != FIUNET_BF16X2) ||
+        (precision == FIUNET_BF16X2 && !ctx->bilinear) ||
         !make_plan(B, H, W, precision, plan_opts(ctx, H, W, precision), p)) {
         g_err = "fiunet_workspace_bytes: bad arguments";
         return 0;
@@ -877,7 +1021,7 @@ int fiunet_forward_strip(fiunet_ctx* ctx, const float* frame1, const float* fram
     if (y_origin + H != H_image && H % 16 != 0)
         return fail(FIUNET_ERR_BAD_SHAPE, "strip: rows must be a multiple of 16 unless it ends the image");
     if (!ctx->loaded) return fail(FIUNET_ERR_NOT_LOADED, "fiunet_forward before fiunet_load_weights");
-    if (precision != FIUNET_FP32 && precision != FIUNET_BF16)
+    if (precision != FIUNET_FP32 && precision != FIUNET_BF16 && precision != FIUNET_BF16X2)
         return fail(FIUNET_ERR_INVALID_ARG, "bad precision");
     if (B < 1) return fail(FIUNET_ERR_INVALID_ARG, "B < 1");
     if (H < 16 || W < 16)
@@ -890,6 +1034,8 @@ int fiunet_forward_strip(fiunet_ctx* ctx, const float* frame1, const float* fram
     if ((uintptr_t)workspace & 255) return fail(FIUNET_ERR_INVALID_ARG, "workspace not 256-B aligned");
     HIP_TRY(hipSetDevice(ctx->device));
     hipStream_t s = (hipStream_t)stream;
+    if (precision == FIUNET_BF16X2)
+        return forward_x2(ctx, frame1, frame2, out, B, H, W, (char*)workspace, p, s, y_origin, H_image, nullptr);
     if (precision == FIUNET_BF16)
         return forward_impl<__bf16>(ctx, frame1, frame2, out, B, H, W, (char*)workspace, p, s, y_origin,
                                     H_image);
@@ -948,7 +1094,9 @@ int fiunet_forward_u8(fiunet_ctx* ctx, const uint8_t* frame1, const uint8_t* fra
     const uint8_t* u1 = in_f32 ? nullptr : frame1;
     const uint8_t* u2 = in_f32 ? nullptr : frame2;
     uint8_t* ou = out_f32 ? nullptr : out;
-    if (precision == FIUNET_BF16)
+    if (precision == FIUNET_BF16X2)
+        rc = forward_x2(ctx, a, b, o, B, H, W, ws, p, s, 0, H, ou);
+    else if (precision == FIUNET_BF16)
         rc = forward_impl<__bf16>(ctx, a, b, o, B, H, W, ws, p, s, 0, H, u1, u2, ou);
     else
         rc = forward_impl<float>(ctx, a, b, o, B, H, W, ws, p, s, 0, H, u1, u2, ou);
@@ -1163,6 +1311,8 @@ int fiunet_debug_read_activation(fiunet_ctx* ctx, const void* workspace, int B, 
     if (!ctx || !workspace || !dst || tap < 0 || tap >= NCONV)
         return fail(FIUNET_ERR_INVALID_ARG, "bad argument");
     Plan p;
+    if (precision == FIUNET_BF16X2)
+        return fail(FIUNET_ERR_UNSUPPORTED, "read-back is not available in the bf16x2 precision (two-piece activations)");
     if (!(ctx->flags & FIUNET_OPT_KEEP_ALL))
         return fail(FIUNET_ERR_INVALID_ARG, "read-back needs FIUNET_OPT_KEEP_ALL set for the forward: without it "
                                             "activations share workspace bytes and are overwritten");

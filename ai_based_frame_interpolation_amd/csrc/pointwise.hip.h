@@ -442,6 +442,86 @@ __global__ __launch_bounds__(256) void upsample_kernel(const ConvArgs a, T* __re
     }
 }
 
+// ---- "bf16x2" precision: helpers around the two-piece [hi | hi | lo] activation layout (conv3x3_mfma.hip.h, EPI_*_X2)
+__device__ __forceinline__ void x2_split_store(char* o, size_t block_bytes, const float (&v)[8])
+{
+    unsigned h[4], l[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        h[i] = pack_bf16x2_pk(v[2 * i], v[2 * i + 1]);
+        l[i] = pack_bf16x2_pk(v[2 * i] - __uint_as_float(h[i] << 16), v[2 * i + 1] - __uint_as_float(h[i] & 0xffff0000u));
+    }
+    const uint4 hv = make_uint4(h[0], h[1], h[2], h[3]);
+    *reinterpret_cast<uint4*>(o) = hv;
+    *reinterpret_cast<uint4*>(o + block_bytes) = hv;
+    *reinterpret_cast<uint4*>(o + 2 * block_bytes) = make_uint4(l[0], l[1], l[2], l[3]);
+}
+__device__ __forceinline__ void x2_load(const char* p, size_t block_bytes, float (&v)[8])
+{
+    float hi[8], lo[8];
+    chunk_unpack<__bf16>(ldg16(p), hi);
+    chunk_unpack<__bf16>(ldg16(p + 2 * block_bytes), lo);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) v[i] = hi[i] + lo[i];   // exact: the two pieces do not overlap
+}
+
+// fp32 blocked tensor [B][C/16][H][W][16] (the exact-fp32 stem's output) -> [B][3 * C/32][H][W][32] bf16, blocks [hi | hi | lo]
+__global__ __launch_bounds__(256) void x2_split_kernel(const float* __restrict__ src, char* __restrict__ dst, int B, int HW, int C)
+{
+    const int np = C / 32;
+    const size_t total = (size_t)B * np * HW * 4;
+    const size_t blk = (size_t)np * HW * 64;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        const int ch = (int)(i & 3);
+        size_t r = i >> 2;
+        const size_t pix = r % HW; r /= HW;
+        const int p = (int)(r % np), b = (int)(r / np);
+        const int c0 = p * 32 + ch * 8;                        // first of this chunk's 8 channels
+        const float* s = src + (((size_t)b * (C / 16) + c0 / 16) * HW + pix) * 16 + c0 % 16;
+        float v[8];
+        const float4 a0 = *reinterpret_cast<const float4*>(s), a1 = *reinterpret_cast<const float4*>(s + 4);
+        v[0] = a0.x; v[1] = a0.y; v[2] = a0.z; v[3] = a0.w; v[4] = a1.x; v[5] = a1.y; v[6] = a1.z; v[7] = a1.w;
+        x2_split_store(dst + (size_t)b * 3 * blk + ((size_t)p * HW + pix) * 64 + ch * 16, blk, v);
+    }
+}
+
+// Upsample(x2, bilinear, align_corners=True) + F.pad of a two-piece tensor: the fp32 value hi + lo of the four
+// neighbours, aten's association in fp32 (chunk_bilerp's), split again.  a.src1 = low-res [B][3 * C1/32][lowH][lowW][32],
+// dst = [B][3 * C1/32][H][W][32]; a.C1 = the REAL channel count.  One thread per (pixel, 16-B chunk).
+__global__ __launch_bounds__(256) void x2_upsample_kernel(const ConvArgs a, char* __restrict__ dst)
+{
+    const int np = a.C1 / 32;
+    const size_t HW = (size_t)a.H * a.W, lHW = (size_t)a.lowH * a.lowW;
+    const size_t total = (size_t)a.B * np * HW * 4;
+    const size_t blk = (size_t)np * HW * 64, lblk = (size_t)np * lHW * 64;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        const int ch = (int)(i & 3);
+        size_t r = i >> 2;
+        const int x = (int)(r % a.W); r /= a.W;
+        const int y = (int)(r % a.H); r /= a.H;
+        const int p = (int)(r % np), b = (int)(r / np);
+        const UpCoord u = up_coord(a, y, x);
+        float o[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) o[k] = 0.f;
+        if (u.ok) {
+            const char* base = (const char*)a.src1 + (size_t)b * 3 * lblk + (size_t)p * lHW * 64 + ch * 16;
+            float v00[8], v01[8], v10[8], v11[8];
+            x2_load(base + ((size_t)u.y0 * a.lowW + u.x0) * 64, lblk, v00);
+            x2_load(base + ((size_t)u.y0 * a.lowW + u.x1) * 64, lblk, v01);
+            x2_load(base + ((size_t)u.y1 * a.lowW + u.x0) * 64, lblk, v10);
+            x2_load(base + ((size_t)u.y1 * a.lowW + u.x1) * 64, lblk, v11);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const float top = fmaf(u.lx, v01[k], __fmul_rn(u.hx, v00[k]));
+                const float bot = fmaf(u.lx, v11[k], __fmul_rn(u.hx, v10[k]));
+                o[k] = fmaf(u.ly, bot, __fmul_rn(u.hy, top));
+            }
+        }
+        x2_split_store(dst + (size_t)b * 3 * blk + ((size_t)p * HW + (size_t)y * a.W + x) * 64 + ch * 16, blk, o);
+    }
+}
+
 // thread = pixel; reads 64 channels, writes nc fp32 planes
 template <typename T>
 __global__ __launch_bounds__(256) void head1x1_kernel(const T* __restrict__ src,

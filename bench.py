@@ -511,12 +511,16 @@ def main():
             dist.destroy_process_group()
         return
 
-    cpu_baseline = parity = fp32 = rgb = None
+    cpu_baseline = parity = fp32 = rgb = x2 = None
     if world == 1 and default_workload and not args.no_fp32:
         try:
             rgb = rgb_leg(dev)
         except Exception as e:  # an extra leg must never cost the headline line
             rgb = {"error": f"{type(e).__name__}: {e}"}
+        try:
+            x2 = bf16x2_leg(dev)
+        except Exception as e:
+            x2 = {"error": f"{type(e).__name__}: {e}"}
     if world == 1 and default_workload and not args.no_fp32:
         try:
             fp32 = fp32_legs(dev)
@@ -525,7 +529,7 @@ def main():
     if world == 1 and not args.no_cpu_baseline:
         cpu_baseline, parity = cpu_legs(dev, args.precision)
     print(json.dumps(headline(args, world, elapsed, rows, nfw, default_workload, video_res, tile_res,
-                              cpu_baseline, parity, fp32, power, rgb)))
+                              cpu_baseline, parity, fp32, power, rgb, x2)))
     if dist is not None:
         dist.destroy_process_group()
 
@@ -645,6 +649,50 @@ def rgb_leg(dev, steps=10, warm=2):
                                "out_absmax": round(float(ref.abs().max()), 4)}}
 
 
+def bf16x2_leg(dev):
+    """Round 4: the fp32 CONTRACT (north_star: |d|_inf <= 1e-3 against the reference's PyTorch-CPU forward) met on
+    the bf16 matrix cores - precision "bf16x2": activations and weights as two bf16 pieces (16 significant bits),
+    wh*xh + wl*xh + wh*xl per product with fp32 accumulation, exact-fp32 stem and head.  Same two workloads and
+    protocol as `fp32` (BASELINE configs[1] and batch 4 of 1080p pairs), plus the measured error against the CPU
+    oracle on the bench network.  The exact-fp32 figures stay in `fp32`: this is an extra mode, not a substitute."""
+    from oracle import unet_oracle as O
+    model = make_bench_model("bf16x2").to(dev).eval()
+    out = {}
+    for key, b, h, w, warm, steps in (("config2_b16_256x256", 16, 256, 256, 10, 50), ("b4_1080p", 4, 1080, 1920, 1, 5)):
+        gen = torch.Generator(device=dev).manual_seed(1)
+        f1 = torch.rand(b, 1, h, w, device=dev, generator=gen) * 2 - 1
+        f2 = torch.rand(b, 1, h, w, device=dev, generator=gen) * 2 - 1
+        for _ in range(warm):
+            model(f1, f2)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        torch.cuda.synchronize()
+        e0.record()
+        for _ in range(steps):
+            model(f1, f2)
+        e1.record()
+        torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1) / steps
+        fps = b / (ms * 1e-3)
+        out[key] = {"value": round(fps, 2), "unit": "frames/s", "ms_per_step": round(ms, 4), "steps": steps, "warmup": warm,
+                    "dtype": "bf16x2 (two-piece bf16 operands, 3 MFMAs per product, fp32 accumulate)",
+                    "workload": f"batch={b} {w}x{h} synthetic frame pairs",
+                    "algorithmic_tflops": round(fps * conv_flops(h, w) / 1e12, 2),
+                    "executed_mfma_frac_of_bf16_peak": round(3 * fps * conv_flops(h, w) / 1e12 / PEAK_TFLOPS["bf16"], 4)}
+        del f1, f2
+    sd = {k: v.detach().cpu() for k, v in model.state_dict().items()}
+    g = torch.Generator().manual_seed(9)
+    s1, s2 = torch.rand(1, 1, 270, 480, generator=g) * 2 - 1, torch.rand(1, 1, 270, 480, generator=g) * 2 - 1
+    ref = O.unet_forward(sd, s1, s2)
+    got = model(s1.to(dev), s2.to(dev)).cpu()
+    model.precision = "fp32"
+    got32 = model(s1.to(dev), s2.to(dev)).cpu()
+    out["parity_270x480"] = {"max_abs_vs_cpu_ref": round(float((got - ref).abs().max()), 8),
+                             "rel_l2_vs_cpu_ref": round(float((got - ref).norm() / ref.norm()), 9),
+                             "exact_fp32_max_abs_vs_cpu_ref": round(float((got32 - ref).abs().max()), 8),
+                             "out_absmax": round(float(ref.abs().max()), 4), "contract_max_abs": 1e-3}
+    return out
+
+
 def fp32_legs(dev):
     """The reference's own arithmetic (fp32) on the driver-timed line: BASELINE configs[1] (batch 16 of
     256x256 pairs, SURVEY 8d config 2 protocol: 10 warm-up + 50 timed, HIP events around the forwards on
@@ -688,7 +736,7 @@ def fp32_legs(dev):
 
 
 def headline(args, world, elapsed, rows, nfw, default_workload, video_res, tile_res, cpu_baseline, parity,
-             fp32=None, power=None, rgb=None):
+             fp32=None, power=None, rgb=None, x2=None):
     b, h, w = args.batch, args.height, args.width
     fps = world * b * args.steps / elapsed
     ms_step = elapsed / args.steps * 1e3
@@ -751,6 +799,8 @@ def headline(args, world, elapsed, rows, nfw, default_workload, video_res, tile_
         result["fp32"] = fp32
     if rgb is not None:
         result["rgb_6to3"] = rgb
+    if x2 is not None:
+        result["fp32_contract_on_bf16_pipe"] = x2
     if power is not None:
         result["power"] = power
         if power.get("mfma_peak_at_sclk_tflops"):

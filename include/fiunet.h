@@ -37,7 +37,14 @@ enum fiunet_status {
 /* Arithmetic type of the conv path.  FP32: fp32 storage, exact-fp32 MFMA (v_mfma_f32_16x16x4_f32).
  * BF16: bf16 activations/weights in HBM, v_mfma_f32_16x16x32_bf16 with fp32 accumulation; the
  * first (Cin=2) conv and the final 1x1 conv stay fp32 arithmetic in both modes. */
-enum fiunet_precision { FIUNET_FP32 = 0, FIUNET_BF16 = 1 };
+enum fiunet_precision {
+    FIUNET_FP32 = 0,   /* exact fp32: v_mfma_f32_16x16x4_f32 (the reference's own arithmetic) */
+    FIUNET_BF16 = 1,   /* bf16 storage and MFMA operands, fp32 accumulation */
+    FIUNET_BF16X2 = 2  /* round 4: the fp32 CONTRACT (|d| <= 1e-3) on the bf16 pipe - every activation and weight is two bf16
+                          pieces (hi + lo, 16 significant bits), a product is wh*xh + wl*xh + wh*xl with fp32 accumulation
+                          (~1e-5 relative end to end); fp32 frames in, fp32 logits out, exact-fp32 stem and head.
+                          bilinear=True only; the ablation / read-back options are not available in this mode */
+};
 
 /* Bit flags for fiunet_set_options. */
 enum fiunet_option {

@@ -411,3 +411,69 @@ def test_convtranspose_variant_larger_frame_bands_and_u8(convt_model, dev, prec)
     got = convt_model.forward_u8(a.to(dev), b.to(dev)).cpu().numpy()
     want = O.postprocess_tensor(O.unet_forward(sd, O.preprocess_array(a[0, 0].numpy()), O.preprocess_array(b[0, 0].numpy())))
     assert O.psnr_u8(want, got[0, 0]) >= (60.0 if prec == "fp32" else 35.0)
+
+
+# ---- precision "bf16x2": the fp32 CONTRACT on the bf16 matrix cores (two-piece activations and weights) -------------
+@pytest.mark.parametrize("name", ["b1_32x48", "b2_64x64", "b1_17x31", "b1_16x16", "b1_135x240", "b1_256x256"])
+def test_bf16x2_meets_the_fp32_contract_on_the_reference_goldens(model, dev, golden_dir, name):
+    """north_star: |d|_inf <= 1e-3 against the reference's PyTorch-CPU forward.  bf16x2 computes every product as
+    wh*xh + wl*xh + wh*xl on the bf16 MFMAs (fp32 accumulation; activations stored with 16 significant bits), the
+    stem and the head in exact fp32: measured max |d| 2e-5 .. 1.8e-4 on outputs of magnitude 1-3.5 (rel-L2 1.5e-5;
+    the exact-fp32 path: 1e-5 / 1e-6).  Asserted at 1e-3 absolute AND 2e-4 relative to the output range."""
+    g = np.load(os.path.join(golden_dir, f"out_{name}.npz"))
+    f1, f2, ref = torch.from_numpy(g["frame1"]), torch.from_numpy(g["frame2"]), torch.from_numpy(g["out"])
+    model.precision = "bf16x2"
+    model.set_options()
+    out = model(f1.to(dev), f2.to(dev)).cpu()
+    model.precision = "fp32"
+    d = (out - ref).abs().max().item()
+    assert out.shape == ref.shape and out.dtype == torch.float32
+    assert d <= FP32_TOL and d <= 2e-4 * max(1.0, ref.abs().max().item()), d
+    assert ((out - ref).norm() / ref.norm()).item() <= 1e-4
+
+
+def test_bf16x2_larger_frames_bands_u8_rgb_and_psnr(dev, seeded_sd):
+    """A frame large enough for the 32-wide tiles and the un-split kernels, two row bands of it (bit-identical: the
+    same kernels, whole-image upsample coordinates), the uint8 path, the RGB 6 -> 3 variant, and the PSNR criterion
+    on an interpolating checkpoint (identical to the CPU reference's, as for the exact-fp32 path)."""
+    from ai_based_frame_interpolation_amd import tiling
+    m = P.FrameInterpolationUNet(bilinear=True, precision="bf16x2")
+    m.load_state_dict(seeded_sd)
+    m = m.to(dev).eval()
+    f1, f2 = O.make_frames(43, 2, 272, 208)
+    ref = O.unet_forward(seeded_sd, f1, f2)
+    out = m(f1.to(dev), f2.to(dev))
+    d = (out.cpu() - ref).abs().max().item()
+    assert d <= FP32_TOL and d <= 2e-4 * max(1.0, ref.abs().max().item()), d
+    tiled = tiling.forward_tiled(m.forward_strip, f1.to(dev), f2.to(dev), 2)
+    assert torch.equal(tiled, out)
+    assert torch.equal(m(f1[:1].to(dev), f2[:1].to(dev)), out[:1])       # batch invariance (no K-split in this mode)
+    # uint8 in / out
+    gen = torch.Generator().manual_seed(8)
+    a = torch.randint(0, 256, (1, 1, 64, 80), dtype=torch.uint8, generator=gen)
+    b = torch.randint(0, 256, (1, 1, 64, 80), dtype=torch.uint8, generator=gen)
+    got = m.forward_u8(a.to(dev), b.to(dev)).cpu().numpy()
+    want = O.postprocess_tensor(O.unet_forward(seeded_sd, O.preprocess_array(a[0, 0].numpy()), O.preprocess_array(b[0, 0].numpy())))
+    assert O.psnr_u8(want, got[0, 0]) >= 60.0
+    # RGB 6 -> 3
+    mr, sdr = _rgb_model(dev, 77, "bf16x2")
+    r1, r2 = O.make_frames(34, 1, 45, 71, c=3)
+    rr = O.unet_forward(sdr, r1, r2)
+    dr = (mr(r1.to(dev), r2.to(dev)).cpu() - rr).abs().max().item()
+    assert dr <= FP32_TOL and dr <= 2e-4 * max(1.0, rr.abs().max().item()), dr
+    # PSNR criterion (north_star: within 0.05 dB of the CPU reference)
+    sdi = O.make_interpolating_state_dict()
+    mi = P.FrameInterpolationUNet(bilinear=True, precision="bf16x2")
+    mi.load_state_dict(sdi)
+    mi = mi.to(dev).eval()
+    x, truth, z = S.triplet(256, 256, device="cpu", seed=3)
+    ref_u8 = O.postprocess_tensor(O.unet_forward(sdi, O.preprocess_array(x.numpy()), O.preprocess_array(z.numpy())))
+    hip_u8 = mi.forward_u8(x[None, None].to(dev), z[None, None].to(dev))[0, 0].cpu().numpy()
+    assert abs(O.psnr_u8(truth.numpy(), hip_u8) - O.psnr_u8(truth.numpy(), ref_u8)) <= 0.002
+    # not available in this mode: the ConvTranspose2d decoder, the per-layer read-back
+    mc = P.FrameInterpolationUNet(precision="bf16x2")
+    mc.load_state_dict(O.make_seeded_state_dict(1234, bilinear=False))
+    with pytest.raises(RuntimeError):
+        mc.to(dev).eval()(f1[:1, :, :32, :32].contiguous().to(dev), f2[:1, :, :32, :32].contiguous().to(dev))
+    with pytest.raises(RuntimeError):
+        m.debug_activations(f1[:1].to(dev), f2[:1].to(dev))
