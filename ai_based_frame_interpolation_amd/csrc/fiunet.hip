@@ -131,7 +131,6 @@ struct Plan {
     size_t scratch_off;
     size_t up_off[NCONV];  // upsampled half of a concat input, where it is materialised (else unused)
     size_t slab_off;   // split-K partial sums (small problems), kSlabBytes
-    size_t stem32_off; // FIUNET_BF16X2: the exact-fp32 stem's output before it is split into pieces
     size_t total;
 };
 
@@ -197,8 +196,6 @@ bool make_plan(int B, int H, int W, int precision, const PlanOpts& o, Plan& p)
                                      (o.convt ? o.cout[kSrc1[i]] / 2 : o.cout[kSrc1[i]]) * es), i,
                             o.keep_all ? END : i, &p.up_off[i]});
     }
-    p.stem32_off = 0;
-    if (o.x2) bufs.push_back({align256((size_t)B * H * W * 64 * 4), 0, 1, &p.stem32_off});
     p.scratch_off = 0;
     if (o.unfused && !o.convt)  // ablation path: concat tensor (<= 128 ch at level 0), rewritten by every Up block
         bufs.push_back({align256((size_t)B * H * W * 128 * es), 0, END, &p.scratch_off});
@@ -655,7 +652,7 @@ int forward_impl(fiunet_ctx* ctx, const float* f1, const float* f2, float* out, 
 
 // FIUNET_BF16X2: the fp32 contract on the bf16 pipe (include/fiunet.h).  Activations are two-piece tensors of 3 * C bf16
 // channels [hi | hi | lo]; every conv is the plain bf16 direct kernel over them with the [wh | wl | wh] weights and a
-// splitting epilogue (EPI_PLAIN_X2 / EPI_POOL_X2), the stem is the exact-fp32 kernel followed by a split pass, the
+// splitting epilogue (EPI_PLAIN_X2 / EPI_POOL_X2), the stem is the exact-fp32 kernel with a splitting epilogue, the
 // upsampled halves are always materialised (x2_upsample_kernel: fp32 interpolation of hi + lo), the head is the usual
 // fused fp32 reduction.  No K-split (small frames run the un-split kernels), no ablation / read-back options.
 int forward_x2(fiunet_ctx* ctx, const float* f1, const float* f2, float* out, int B, int H, int W, char* ws,
@@ -678,24 +675,20 @@ int forward_x2(fiunet_ctx* ctx, const float* f1, const float* f2, float* out, in
         ctx->ev_used += NCONV + 1;
         HIP_TRY(hipEventRecord(ev[0], s));
     }
-    {   // conv 0: exact-fp32 stem (no dither: this is the fp32-contract path), then the split into pieces
+    {   // conv 0: exact-fp32 stem (no dither: this is the fp32-contract path), its epilogue splits into the two pieces
         const ConvWeights& cw = ctx->conv[0];
-        float* stem32 = (float*)(ws + p.stem32_off);
         const long long nruns = (long long)B * H * (((W + 15) / 16 + 7) / 8);
         dim3 grid((unsigned)std::min<long long>((nruns + 3) / 4, 256 * 64));
         if (ctx->cf == 1)
-            hipLaunchKernelGGL((conv3x3_first_kernel<float, 1>), grid, dim3(256), 0, s, f1, f2, (const float*)cw.w_f32,
-                               cw.scale, cw.shift, stem32, B, H, W, 0.f);
+            hipLaunchKernelGGL((conv3x3_first_kernel<__bf16, 1, true>), grid, dim3(256), 0, s, f1, f2, (const float*)cw.w_f32,
+                               cw.scale, cw.shift, (__bf16*)act(0), B, H, W, 0.f);
         else
-            hipLaunchKernelGGL((conv3x3_first_kernel<float, 3>), grid, dim3(256), 0, s, f1, f2, (const float*)cw.w_f32,
-                               cw.scale, cw.shift, stem32, B, H, W, 0.f);
-        HIP_TRY(hipGetLastError());
-        const size_t n = (size_t)B * 2 * H * W * 4;
-        hipLaunchKernelGGL(x2_split_kernel, dim3(grid_for(n)), dim3(256), 0, s, stem32, act(0), B, H * W, 64);
+            hipLaunchKernelGGL((conv3x3_first_kernel<__bf16, 3, true>), grid, dim3(256), 0, s, f1, f2, (const float*)cw.w_f32,
+                               cw.scale, cw.shift, (__bf16*)act(0), B, H, W, 0.f);
         HIP_TRY(hipGetLastError());
         if (ev) {
             HIP_TRY(hipEventRecord(ev[1], s));
-            ctx->layer_name[0] = "conv3x3_first_kernel<f32> + x2_split_kernel";
+            ctx->layer_name[0] = "conv3x3_first_kernel<f32 arithmetic, two-piece output>";
             ctx->layer_flops[0] = 2.0 * B * H * W * 9.0 * cw.cin * cw.cout;
         }
     }

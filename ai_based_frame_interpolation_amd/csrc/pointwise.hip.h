@@ -16,6 +16,29 @@
 
 namespace fiunet {
 
+// ---- "bf16x2" precision: helpers around the two-piece [hi | hi | lo] activation layout (conv3x3_mfma.hip.h, EPI_*_X2)
+__device__ __forceinline__ void x2_split_store(char* o, size_t block_bytes, const float (&v)[8])
+{
+    unsigned h[4], l[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        h[i] = pack_bf16x2_pk(v[2 * i], v[2 * i + 1]);
+        l[i] = pack_bf16x2_pk(v[2 * i] - __uint_as_float(h[i] << 16), v[2 * i + 1] - __uint_as_float(h[i] & 0xffff0000u));
+    }
+    const uint4 hv = make_uint4(h[0], h[1], h[2], h[3]);
+    *reinterpret_cast<uint4*>(o) = hv;
+    *reinterpret_cast<uint4*>(o + block_bytes) = hv;
+    *reinterpret_cast<uint4*>(o + 2 * block_bytes) = make_uint4(l[0], l[1], l[2], l[3]);
+}
+__device__ __forceinline__ void x2_load(const char* p, size_t block_bytes, float (&v)[8])
+{
+    float hi[8], lo[8];
+    chunk_unpack<__bf16>(ldg16(p), hi);
+    chunk_unpack<__bf16>(ldg16(p + 2 * block_bytes), lo);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) v[i] = hi[i] + lo[i];   // exact: the two pieces do not overlap
+}
+
 // Stem conv on the fp32 matrix cores (exact fp32: v_mfma_f32_16x16x4_f32 is a k-ordered fmaf
 // chain).  One wave = one 16-pixel row segment x 64 couts per iteration:
 //   A (weights)  [16 couts][4 k]  kept in registers for the whole kernel (4 cout tiles x KG k-groups)
@@ -23,7 +46,9 @@ namespace fiunet {
 // The A rows are permuted so that lane (pixel, q) ends up with couts 16q..16q+15: its epilogue
 // is 32 (bf16) / 64 (fp32) contiguous bytes and the 4 lanes of a pixel cover its whole 64-channel
 // NHWC record.  K = 18 (gray) or 54 (RGB) is zero-padded to a multiple of 4.
-template <typename T, int CF>
+// X2 (precision bf16x2): the exact-fp32 result is split into two bf16 pieces right here and written as the [hi | hi | lo]
+// tensor of 3 * 64 channels (T = bf16 is then only the element type of `dst`; no dither: this is the fp32-contract path).
+template <typename T, int CF, bool X2 = false>
 __global__ __launch_bounds__(256) void conv3x3_first_kernel(
     const float* __restrict__ f1, const float* __restrict__ f2, const float* __restrict__ w,
     const float* __restrict__ scale, const float* __restrict__ shift, T* __restrict__ dst, int B,
@@ -83,7 +108,7 @@ __global__ __launch_bounds__(256) void conv3x3_first_kernel(
             for (int g = 0; g < KG; ++g) {
                 const int xx = x + dxs[g];
                 v[g] = (xx >= 0 && xx < W) ? p[g][(xt - xt0) * 16 + dxs[g]] : 0.f;
-                if constexpr (sizeof(T) == 2) {  // the conv's zero padding stays exactly zero
+                if constexpr (sizeof(T) == 2 && !X2) {  // the conv's zero padding stays exactly zero
                     // (row and frame of this k-slot are re-derived from koff through an opaque copy of y, so
                     // that hipcc does not hoist one more register per k-group out of the tile loop: the RGB
                     // instantiation would drop to one wave per SIMD)
@@ -116,7 +141,17 @@ __global__ __launch_bounds__(256) void conv3x3_first_kernel(
 #pragma unroll
                 for (int j = 0; j < 4; ++j)
                     o[ct * 4 + j] = fmaxf(fmaf(acc[ct][j], sc[ct * 4 + j], sh[ct * 4 + j]), 0.f);
-            if (x < W) {
+            if constexpr (X2) {
+                if (x < W) {   // couts lc*16 .. +15 = two 16-B chunks of plane lc / 2; blocks of 2 planes per image
+                    const size_t blk = (size_t)2 * H * W * 64;
+                    char* op = (char*)dst + (size_t)b * 3 * blk + blk_off(lc >> 1, y, x, H, W) + (size_t)(lc & 1) * 32;
+                    float c0[8], c1[8];
+#pragma unroll
+                    for (int c = 0; c < 8; ++c) { c0[c] = o[c]; c1[c] = o[8 + c]; }
+                    x2_split_store(op, blk, c0);
+                    x2_split_store(op + 16, blk, c1);
+                }
+            } else if (x < W) {
                 // couts lc*16 .. lc*16+15 of this pixel: half a plane record (bf16) / one plane (fp32)
                 constexpr int NE = Elem<T>::NE, PL = Elem<T>::PL;
                 char* op = (char*)dst + (size_t)b * H * W * 64 * sizeof(T) +
@@ -439,49 +474,6 @@ __global__ __launch_bounds__(256) void upsample_kernel(const ConvArgs a, T* __re
             if (!ux.ok) v = make_uint4(0u, 0u, 0u, 0u);
         }
         *reinterpret_cast<uint4*>(out + (size_t)y * a.W * 64) = v;
-    }
-}
-
-// ---- "bf16x2" precision: helpers around the two-piece [hi | hi | lo] activation layout (conv3x3_mfma.hip.h, EPI_*_X2)
-__device__ __forceinline__ void x2_split_store(char* o, size_t block_bytes, const float (&v)[8])
-{
-    unsigned h[4], l[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        h[i] = pack_bf16x2_pk(v[2 * i], v[2 * i + 1]);
-        l[i] = pack_bf16x2_pk(v[2 * i] - __uint_as_float(h[i] << 16), v[2 * i + 1] - __uint_as_float(h[i] & 0xffff0000u));
-    }
-    const uint4 hv = make_uint4(h[0], h[1], h[2], h[3]);
-    *reinterpret_cast<uint4*>(o) = hv;
-    *reinterpret_cast<uint4*>(o + block_bytes) = hv;
-    *reinterpret_cast<uint4*>(o + 2 * block_bytes) = make_uint4(l[0], l[1], l[2], l[3]);
-}
-__device__ __forceinline__ void x2_load(const char* p, size_t block_bytes, float (&v)[8])
-{
-    float hi[8], lo[8];
-    chunk_unpack<__bf16>(ldg16(p), hi);
-    chunk_unpack<__bf16>(ldg16(p + 2 * block_bytes), lo);
-#pragma unroll
-    for (int i = 0; i < 8; ++i) v[i] = hi[i] + lo[i];   // exact: the two pieces do not overlap
-}
-
-// fp32 blocked tensor [B][C/16][H][W][16] (the exact-fp32 stem's output) -> [B][3 * C/32][H][W][32] bf16, blocks [hi | hi | lo]
-__global__ __launch_bounds__(256) void x2_split_kernel(const float* __restrict__ src, char* __restrict__ dst, int B, int HW, int C)
-{
-    const int np = C / 32;
-    const size_t total = (size_t)B * np * HW * 4;
-    const size_t blk = (size_t)np * HW * 64;
-    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
-        const int ch = (int)(i & 3);
-        size_t r = i >> 2;
-        const size_t pix = r % HW; r /= HW;
-        const int p = (int)(r % np), b = (int)(r / np);
-        const int c0 = p * 32 + ch * 8;                        // first of this chunk's 8 channels
-        const float* s = src + (((size_t)b * (C / 16) + c0 / 16) * HW + pix) * 16 + c0 % 16;
-        float v[8];
-        const float4 a0 = *reinterpret_cast<const float4*>(s), a1 = *reinterpret_cast<const float4*>(s + 4);
-        v[0] = a0.x; v[1] = a0.y; v[2] = a0.z; v[3] = a0.w; v[4] = a1.x; v[5] = a1.y; v[6] = a1.z; v[7] = a1.w;
-        x2_split_store(dst + (size_t)b * 3 * blk + ((size_t)p * HW + pix) * 64 + ch * 16, blk, v);
     }
 }
 
