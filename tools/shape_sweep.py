@@ -14,7 +14,7 @@ n = int(sys.argv[1]) if len(sys.argv) > 1 else 40
 rng = np.random.default_rng(77)
 shapes = [(int(rng.integers(1, 5)), int(rng.integers(16, 320)), int(rng.integers(16, 420))) for _ in range(n)]
 shapes += [(2, 270, 480), (3, 540, 960), (9, 135, 241), (1, 1080, 1920), (5, 272, 528)]
-worst32 = worst16 = 0.0
+worst32 = worst16 = worstx2 = 0.0
 t0 = time.time()
 for i, (b, h, w) in enumerate(shapes):
     f1, f2 = O.make_frames(9000 + i, b, h, w)
@@ -23,6 +23,10 @@ for i, (b, h, w) in enumerate(shapes):
     m.precision = "fp32"; m.set_options()
     o32 = m(g1, g2).cpu()
     d = (o32 - ref).abs().max().item() / max(1.0, ref.abs().max().item())
+    m.precision = "bf16x2"
+    ox2 = m(g1, g2).cpu()
+    dx2 = (ox2 - ref).abs().max().item()
+    worstx2 = max(worstx2, dx2 / max(1.0, ref.abs().max().item()))
     m.precision = "bf16"
     o16 = m(g1, g2)
     rel = ((o16.cpu() - ref).norm() / ref.norm()).item()
@@ -31,7 +35,8 @@ for i, (b, h, w) in enumerate(shapes):
     m.set_options()
     eq = bool(torch.equal(o16, og)) and ((ou - o16).norm() / o16.norm()).item() <= 3e-2
     worst32, worst16 = max(worst32, d), max(worst16, rel)
-    flag = "" if (d <= 1e-4 and rel <= 2.5e-2 and eq and torch.isfinite(o16).all()) else "  <-- FAIL"
-    print(f"{b}x{h}x{w}: fp32 rel-max {d:.2e}  bf16 rel-L2 {rel:.3e}  default==gather-upsample, unfused close: {eq}{flag}", flush=True)
+    okx2 = dx2 <= 1e-3 and dx2 <= 2e-4 * max(1.0, ref.abs().max().item())   # the fp32 contract, and relative
+    flag = "" if (d <= 1e-4 and rel <= 2.5e-2 and eq and okx2 and torch.isfinite(o16).all()) else "  <-- FAIL"
+    print(f"{b}x{h}x{w}: fp32 rel-max {d:.2e}  bf16x2 max-abs {dx2:.2e}  bf16 rel-L2 {rel:.3e}  default==gather-upsample, unfused close: {eq}{flag}", flush=True)
     if flag: sys.exit(1)
-print(f"SWEEP OK: {len(shapes)} shapes, worst fp32 {worst32:.2e}, worst bf16 {worst16:.3e}, {time.time() - t0:.0f} s")
+print(f"SWEEP OK: {len(shapes)} shapes, worst fp32 {worst32:.2e}, worst bf16x2 (relative to max(1, |ref|)) {worstx2:.2e}, worst bf16 {worst16:.3e}, {time.time() - t0:.0f} s")
