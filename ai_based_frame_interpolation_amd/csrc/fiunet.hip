@@ -346,7 +346,8 @@ inline unsigned grid_for(size_t n);
 template <typename T, int BN, int TH, int TW, int MODE, int EPI>
 int launch_conv_maybe_split(ConvArgs a, hipStream_t s)
 {
-    if constexpr (MODE != SRC_STEM && (EPI == EPI_PLAIN || EPI == EPI_POOL)) {
+    constexpr bool X2 = EPI == EPI_PLAIN_X2 || EPI == EPI_POOL_X2;   // precision bf16x2: two-piece output
+    if constexpr (MODE != SRC_STEM && (EPI == EPI_PLAIN || EPI == EPI_POOL || X2)) {
         const long long nblk = (long long)a.B * ((a.W + TW - 1) / TW) * ((a.H + TH - 1) / TH) * (a.Cout / BN);
         const int nplanes = (a.C0 + a.C1) / Elem<T>::PL;
         int ksplit = (int)std::min<long long>(std::min(nplanes / 2, 16), (256 + nblk - 1) / nblk);
@@ -365,8 +366,14 @@ int launch_conv_maybe_split(ConvArgs a, hipStream_t s)
             if (rc) return rc;
             const size_t n = (size_t)a.B * a.H * a.W * (a.Cout / Elem<T>::NE);
             hipLaunchKernelGGL((splitk_finalize_kernel<T>), dim3(grid_for(n)), dim3(256), 0, s, a.kslab,
-                               ksplit, (const float*)nullptr, a.shift, (T*)a.dst, a.B, a.H, a.W, a.Cout, a.relu);
+                               ksplit, (const float*)nullptr, a.shift, (T*)a.dst, a.B, a.H, a.W, a.Cout, a.relu, X2 ? 1 : 0);
             HIP_TRY(hipGetLastError());
+            if constexpr (EPI == EPI_POOL_X2) {
+                const size_t np2 = (size_t)a.B * (a.Cout / 32) * (a.H / 2) * (a.W / 2) * 4;
+                hipLaunchKernelGGL(x2_maxpool2_kernel, dim3(grid_for(np2)), dim3(256), 0, s, (const char*)a.dst,
+                                   (char*)a.pool_dst, a.B, a.H, a.W, a.Cout);
+                HIP_TRY(hipGetLastError());
+            }
             if constexpr (EPI == EPI_POOL) {
                 const size_t np = (size_t)a.B * (a.H / 2) * (a.W / 2) * (a.Cout * sizeof(T) / 16);
                 hipLaunchKernelGGL((maxpool2_kernel<T>), dim3(grid_for(np)), dim3(256), 0, s,
@@ -654,7 +661,8 @@ int forward_impl(fiunet_ctx* ctx, const float* f1, const float* f2, float* out, 
 // channels [hi | hi | lo]; every conv is the plain bf16 direct kernel over them with the [wh | wl | wh] weights and a
 // splitting epilogue (EPI_PLAIN_X2 / EPI_POOL_X2), the stem is the exact-fp32 kernel with a splitting epilogue, the
 // upsampled halves are always materialised (x2_upsample_kernel: fp32 interpolation of hi + lo), the head is the usual
-// fused fp32 reduction.  No K-split (small frames run the un-split kernels), no ablation / read-back options.
+// fused fp32 reduction.  Small problems K-split like the other precisions (splitk_finalize_kernel writes the two pieces,
+// x2_maxpool2_kernel the pooled copy); no ablation / read-back options.
 int forward_x2(fiunet_ctx* ctx, const float* f1, const float* f2, float* out, int B, int H, int W, char* ws,
                const Plan& p, hipStream_t s, int y_origin, int Hg, uint8_t* out_u8)
 {
@@ -704,7 +712,7 @@ int forward_x2(fiunet_ctx* ctx, const float* f1, const float* f2, float* out, in
         a.relu = 1;
         a.zero_page = ctx->zero_page;
         a.ksplit = 1;
-        a.kslab = nullptr;
+        a.kslab = i == NCONV - 1 ? nullptr : (float*)(ws + p.slab_off);   // small problems: K-split like the other paths
         a.dst = act(i);
         a.src0 = act(kSrc0[i]);
         a.C0 = 3 * ctx->cout[kSrc0[i]];
