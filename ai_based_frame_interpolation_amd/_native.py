@@ -28,7 +28,7 @@ OPT_RNE_WEIGHTS, OPT_NO_DITHER = 32, 64
 #: every symbol include/fiunet.h declares (tests/test_abi.py checks the header against this)
 SYMBOLS = (
     "fiunet_abi_version", "fiunet_last_error_string", "fiunet_create", "fiunet_destroy",
-    "fiunet_set_options", "fiunet_load_weights", "fiunet_workspace_bytes", "fiunet_forward",
+    "fiunet_set_options", "fiunet_load_weights", "fiunet_prepare_precision", "fiunet_workspace_bytes", "fiunet_forward",
     "fiunet_forward_strip",
     "fiunet_workspace_bytes_u8", "fiunet_forward_u8", "fiunet_preprocess_u8",
     "fiunet_postprocess_u8", "fiunet_debug_read_activation", "fiunet_profile_enable",
@@ -82,6 +82,7 @@ def lib() -> ctypes.CDLL:
     L.fiunet_set_options.argtypes = [vp, ctypes.c_uint]
     L.fiunet_load_weights.argtypes = [vp, ci, ctypes.POINTER(ctypes.c_char_p),
                                       ctypes.POINTER(vp), ctypes.POINTER(ctypes.c_int64)]
+    L.fiunet_prepare_precision.argtypes = [vp, ci]
     L.fiunet_workspace_bytes.argtypes = [vp, ci, ci, ci, ci]
     L.fiunet_workspace_bytes.restype = sz
     L.fiunet_workspace_bytes_u8.argtypes = [vp, ci, ci, ci, ci]
@@ -91,7 +92,7 @@ def lib() -> ctypes.CDLL:
     L.fiunet_forward_u8.argtypes = [vp, vp, vp, vp, ci, ci, ci, ci, vp, sz, vp]
     L.fiunet_preprocess_u8.argtypes = [vp, vp, sz, vp]
     L.fiunet_postprocess_u8.argtypes = [vp, vp, sz, vp]
-    L.fiunet_debug_read_activation.argtypes = [vp, vp, ci, ci, ci, ci, ci, vp,
+    L.fiunet_debug_read_activation.argtypes = [vp, vp, ci, ci, ci, ci, ci, vp, sz,
                                                ctypes.POINTER(ci), vp]
     L.fiunet_metrics_workspace_bytes.argtypes = [ci, ci, ci]
     L.fiunet_metrics_workspace_bytes.restype = sz
@@ -125,6 +126,7 @@ class Context:
                                   1 if bilinear else 0), "fiunet_create")
         self.device_index = device_index
         self.frame_channels = frame_channels
+        self._prepared = set()   # precisions whose extra weight copies exist (fiunet_prepare_precision)
 
     def close(self):
         if getattr(self, "_h", None) is not None and self._h:
@@ -154,8 +156,17 @@ class Context:
         check(lib().fiunet_load_weights(
             self._h, n, (ctypes.c_char_p * n)(*names), (ctypes.c_void_p * n)(*ptrs),
             (ctypes.c_int64 * n)(*numels)), "fiunet_load_weights")
+        self._prepared = set()
+
+    def prepare(self, precision: int) -> None:
+        """Weight copies a precision needs beyond the load's (bf16x2: the two-piece copies, built on first use so
+        that fp32 / bf16 users pay neither their memory nor their packing time).  Allocates: not under capture."""
+        if precision not in self._prepared:
+            check(lib().fiunet_prepare_precision(self._h, precision), "fiunet_prepare_precision")
+            self._prepared.add(precision)
 
     def workspace_bytes(self, b, h, w, precision, u8=False) -> int:
+        self.prepare(precision)   # every forward path sizes its workspace first
         fn = lib().fiunet_workspace_bytes_u8 if u8 else lib().fiunet_workspace_bytes
         n = fn(self._h, b, h, w, precision)
         if n == 0:
@@ -208,15 +219,16 @@ class Context:
 
     def read_activation(self, workspace, b, h, w, precision, tap):
         dims = (ctypes.c_int * 3)()
-        from . import unet as _u  # local import: layer table lives with the module mirror
-        c, lv = _u.TAP_CHANNELS[tap], _u.TAP_LEVEL[tap]
-        hh, ww = h >> lv, w >> lv
+        # the library knows the architecture (the ConvTranspose2d decoder is wider at taps 8, 9, 11, 13, 15): ask it
+        # for the tap's dims first (dst = NULL), then hand over a buffer of exactly that size WITH its capacity
+        check(lib().fiunet_debug_read_activation(self._h, None, b, h, w, precision, tap, None, 0, dims, None),
+              "fiunet_debug_read_activation (dims query)")
+        c, hh, ww = tuple(dims)
         dst = torch.empty((b, c, hh, ww), dtype=torch.float32, device=workspace.device)
         s = torch.cuda.current_stream(workspace.device).cuda_stream
         check(lib().fiunet_debug_read_activation(self._h, workspace.data_ptr(), b, h, w, precision,
-                                                 tap, dst.data_ptr(), dims, s),
+                                                 tap, dst.data_ptr(), dst.numel(), dims, s),
               "fiunet_debug_read_activation")
-        assert tuple(dims) == (c, hh, ww), (tuple(dims), (c, hh, ww))
         return dst
 
 

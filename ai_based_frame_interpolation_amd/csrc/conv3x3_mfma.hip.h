@@ -48,7 +48,14 @@ typedef __attribute__((ext_vector_type(4))) float f32x4;
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 
 enum SrcMode { SRC_DIRECT = 0, SRC_POOL = 1 /* host-side tag only */, SRC_CONCAT_UP = 2,
-               SRC_STEM = 3 /* input = stem conv of the raw frame pair, computed in the gather */ };
+               SRC_STEM = 3 /* input = stem conv of the raw frame pair, computed in the gather */,
+               // precision "bf16x2" (the fp32 contract on the bf16 pipe): direct sources whose activations are TWO bf16
+               // pieces, x = hi + lo (16 significant bits), stored [hi planes | lo planes] (4 B per element, fp32's
+               // traffic), weights [wh planes | wl planes]; a product is wh*xh + wl*xh + wh*xl with fp32 accumulation
+               // (the dropped wl*xl term is 2^-16 relative).  The K loop runs three "virtual planes" per real plane of 32
+               // channels - (xh, wh), (xh, wl), (xl, wh) - and the second one reuses the in-tile of the first: every piece
+               // is stored once and gathered once.  Every epilogue of this mode writes the two pieces of its output.
+               SRC_DIRECT_X2 = 4 };
 
 // Activation layout in HBM: plane-major blocked channels-last, [B][C/PL][H][W][PL] with one
 // 64-byte "plane" record per pixel (PL = 32 bf16 / 16 fp32 channels).  A tile row of one plane is
@@ -425,13 +432,7 @@ __device__ __forceinline__ void mma_chunk<float>(f32x4& acc, const uint4& wa, co
 }
 
 enum Epilogue { EPI_PLAIN = 0, EPI_HEAD = 1 /* 1x1 head, 1 class */, EPI_POOL = 2, EPI_HEAD3 = 3 /* 3 classes */,
-                EPI_SPLITK = 4 /* raw fp32 partial sums of a K slice -> slab (small problems) */,
-                // "bf16x2" precision (fp32 contract on the bf16 pipe): every activation is stored as TWO bf16 pieces,
-                // x = hi + lo (16 significant bits), in a tensor of 3 * C channels laid out [hi | hi | lo]; with the
-                // weights packed [wh | wl | wh] a plain bf16 conv over those 3 * C channels computes
-                // wh*xh + wl*xh + wh*xl (the dropped wl*xl term is 2^-16 relative) - the K loop and the gathers are
-                // the bf16 kernel's, unchanged; only the epilogue differs: it splits relu(acc) and writes the three blocks.
-                EPI_PLAIN_X2 = 5, EPI_POOL_X2 = 6 };
+                EPI_SPLITK = 4 /* raw fp32 partial sums of a K slice -> slab (small problems) */ };
 
 // value of the neighbouring lane (lane ^ 1) through DPP quad_perm [1,0,3,2]: no LDS crossbar
 __device__ __forceinline__ unsigned dpp_swap_pairs(unsigned v)
@@ -550,7 +551,7 @@ __device__ __forceinline__ void relu_fma(float& sum, float x, float lo, float w)
 //      y = relu(acc) -> blocked activation records (+ fused pool / head / split-K slab).  acc[m][n]:
 //      accumulator tile m (16 couts) x pixel fragment n of the wave (wc = cout half, wp = pixel
 //      group) of workgroup tile (b, y0, x0), cout tile ct, K slice `split`.
-template <typename T, int BN, int TH, int TW, int EPI>
+template <typename T, int BN, int TH, int TW, int EPI, bool X2 = false>
 __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x4 (&acc)[4][conv_wave_frags(BN, TH, TW)],
                                               int b, int y0, int x0, int ct, int split, int wc, int wp,
                                               int l15, int lc)
@@ -575,73 +576,6 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x4 (&acc)[4]
                 for (int m = 0; m < 4; ++m)
                     *reinterpret_cast<float4*>(o + conv_cout_ofs<T>(m, lc)) =
                         make_float4(acc[m][n][0], acc[m][n][1], acc[m][n][2], acc[m][n][3]);
-            }
-        }
-        return;
-    }
-    if constexpr (EPI == EPI_PLAIN_X2 || EPI == EPI_POOL_X2) {
-        static_assert(sizeof(T) == 2, "the two-piece epilogue belongs to the bf16 kernels");
-        const size_t ps = (size_t)aH * aW * 64;                  // bytes of one 32-channel plane
-        const int npo = a.Cout / 32;                             // planes per block; the tensor has 3 * npo
-        const size_t blk = (size_t)npo * ps;                     // bytes from one block to the next
-        char* const img = (char*)a.dst + (size_t)b * 3 * blk + (size_t)(wbase_c / 32) * ps + lc * 16;
-        const int pH2 = aH >> 1, pW2 = aW >> 1;
-        const size_t pps = (size_t)pH2 * pW2 * 64, pblk = (size_t)npo * pps;
-        char* const pimg = EPI == EPI_POOL_X2 ? (char*)a.pool_dst + (size_t)b * 3 * pblk + (size_t)(wbase_c / 32) * pps + lc * 16
-                                              : nullptr;
-        // 8 consecutive couts of this lane (accumulator tiles 2g, 2g + 1) -> hi and lo chunk, three stores
-        auto put = [&](char* o, size_t block_bytes, const float (&v)[8]) __attribute__((always_inline)) {
-            unsigned h[4], l[4];
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                h[i] = pack_bf16x2_pk(v[2 * i], v[2 * i + 1]);
-                l[i] = pack_bf16x2_pk(v[2 * i] - __uint_as_float(h[i] << 16), v[2 * i + 1] - __uint_as_float(h[i] & 0xffff0000u));
-            }
-            const uint4 hv = make_uint4(h[0], h[1], h[2], h[3]);
-            *reinterpret_cast<uint4*>(o) = hv;
-            *reinterpret_cast<uint4*>(o + block_bytes) = hv;
-            *reinterpret_cast<uint4*>(o + 2 * block_bytes) = make_uint4(l[0], l[1], l[2], l[3]);
-        };
-#pragma unroll
-        for (int n = 0; n < NF; ++n) {
-            const int y = y0 + wp * ROWS_W + n / FR;
-            const int x = x0 + (n % FR) * 16 + l15;
-            if (y < aH && x < aW) {
-#pragma unroll
-                for (int g = 0; g < 2; ++g) {
-                    float v[8];
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        v[j] = a.relu ? fmaxf(acc[2 * g][n][j], 0.f) : acc[2 * g][n][j];
-                        v[4 + j] = a.relu ? fmaxf(acc[2 * g + 1][n][j], 0.f) : acc[2 * g + 1][n][j];
-                    }
-                    put(img + (size_t)(y * aW + x) * 64 + g * ps, blk, v);
-                }
-            }
-        }
-        if constexpr (EPI == EPI_POOL_X2) {
-            // MaxPool2d(2) on the fp32 values (relu is monotonic): rows n / n + FR of this wave, column partner = lane ^ 1
-#pragma unroll
-            for (int n = 0; n < NF; ++n) {
-                if (((n / FR) & 1) != 0) continue;
-                const int y = y0 + wp * ROWS_W + n / FR;
-                const int x = x0 + (n % FR) * 16 + l15;
-                const int py = y >> 1, px = x >> 1;
-                const bool okp = (py < pH2) && (px < pW2) && ((l15 & 1) == 0);
-#pragma unroll
-                for (int g = 0; g < 2; ++g) {
-                    float v[8];
-#pragma unroll
-                    for (int h = 0; h < 2; ++h)
-#pragma unroll
-                        for (int j = 0; j < 4; ++j) {
-                            const float cm = fmaxf(acc[2 * g + h][n][j], acc[2 * g + h][n + FR][j]);
-                            float r = fmaxf(cm, __uint_as_float(dpp_swap_pairs(__float_as_uint(cm))));
-                            if (a.relu) r = fmaxf(r, 0.f);
-                            v[4 * h + j] = r;
-                        }
-                    if (okp) put(pimg + (size_t)(min(py, pH2 - 1) * pW2 + min(px, pW2 - 1)) * 64 + g * pps, pblk, v);
-                }
             }
         }
         return;
@@ -711,6 +645,74 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x4 (&acc)[4]
                 }
             }
         }
+    }
+    if constexpr (X2) {
+        // precision "bf16x2": relu(acc) in fp32 -> two bf16 pieces, stored [hi planes | lo planes] (two 16-B stores per
+        // lane and tile pair; a fused-head conv stores only when the read-back keeps its activation)
+        static_assert(sizeof(T) == 2, "the two-piece epilogue belongs to the bf16 kernels");
+        if (HNC > 0 && !a.dst) return;
+        const size_t ps = (size_t)aH * aW * 64;                  // bytes of one 32-channel plane
+        const int npo = a.Cout / 32;                             // planes per piece; the tensor has 2 * npo
+        const size_t blk = (size_t)npo * ps;                     // bytes from the hi piece to the lo piece
+        char* const img = (char*)a.dst + (size_t)b * 2 * blk + (size_t)(wbase_c / 32) * ps + lc * 16;
+        const int pH2 = aH >> 1, pW2 = aW >> 1;
+        const size_t pps = (size_t)pH2 * pW2 * 64, pblk = (size_t)npo * pps;
+        char* const pimg = EPI == EPI_POOL ? (char*)a.pool_dst + (size_t)b * 2 * pblk + (size_t)(wbase_c / 32) * pps + lc * 16
+                                           : nullptr;
+        // 8 consecutive couts of this lane (accumulator tiles 2g, 2g + 1) -> hi and lo chunk
+        auto put = [&](char* o, size_t block_bytes, const float (&v)[8]) __attribute__((always_inline)) {
+            unsigned h[4], l[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                h[i] = pack_bf16x2_pk(v[2 * i], v[2 * i + 1]);
+                l[i] = pack_bf16x2_pk(v[2 * i] - __uint_as_float(h[i] << 16), v[2 * i + 1] - __uint_as_float(h[i] & 0xffff0000u));
+            }
+            *reinterpret_cast<uint4*>(o) = make_uint4(h[0], h[1], h[2], h[3]);
+            *reinterpret_cast<uint4*>(o + block_bytes) = make_uint4(l[0], l[1], l[2], l[3]);
+        };
+#pragma unroll
+        for (int n = 0; n < NF; ++n) {
+            const int y = y0 + wp * ROWS_W + n / FR;
+            const int x = x0 + (n % FR) * 16 + l15;
+            if (y < aH && x < aW) {
+#pragma unroll
+                for (int g = 0; g < 2; ++g) {
+                    float v[8];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        v[j] = a.relu ? fmaxf(acc[2 * g][n][j], 0.f) : acc[2 * g][n][j];
+                        v[4 + j] = a.relu ? fmaxf(acc[2 * g + 1][n][j], 0.f) : acc[2 * g + 1][n][j];
+                    }
+                    put(img + (size_t)(y * aW + x) * 64 + g * ps, blk, v);
+                }
+            }
+        }
+        if constexpr (EPI == EPI_POOL) {
+            // MaxPool2d(2) on the fp32 values (relu is monotonic): rows n / n + FR of this wave, column partner = lane ^ 1
+#pragma unroll
+            for (int n = 0; n < NF; ++n) {
+                if (((n / FR) & 1) != 0) continue;
+                const int y = y0 + wp * ROWS_W + n / FR;
+                const int x = x0 + (n % FR) * 16 + l15;
+                const int py = y >> 1, px = x >> 1;
+                const bool okp = (py < pH2) && (px < pW2) && ((l15 & 1) == 0);
+#pragma unroll
+                for (int g = 0; g < 2; ++g) {
+                    float v[8];
+#pragma unroll
+                    for (int h = 0; h < 2; ++h)
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            const float cm = fmaxf(acc[2 * g + h][n][j], acc[2 * g + h][n + FR][j]);
+                            float r = fmaxf(cm, __uint_as_float(dpp_swap_pairs(__float_as_uint(cm))));
+                            if (a.relu) r = fmaxf(r, 0.f);
+                            v[4 * h + j] = r;
+                        }
+                    if (okp) put(pimg + (size_t)(min(py, pH2 - 1) * pW2 + min(px, pW2 - 1)) * 64 + g * pps, pblk, v);
+                }
+            }
+        }
+        return;
     }
     if constexpr (EPI == EPI_POOL && PERM) {
         // bf16 + fused MaxPool2d(2) (unet.py:28): a wave owns whole row pairs (fragments n and n + FR), the
@@ -852,8 +854,12 @@ __global__ __launch_bounds__(256, conv_occupancy(BN, TH, TW)) void conv3x3_mfma_
     static_assert(Tile::LDS_BYTES * conv_occupancy(BN, TH, TW) <= 160 * 1024, "LDS per CU");
     constexpr int HNC = EPI == EPI_HEAD ? 1 : (EPI == EPI_HEAD3 ? 3 : 0);  // fused-head classes
     static_assert(HNC == 0 || BN == 64, "fused head needs all 64 couts in one wave");
-    static_assert(MODE == SRC_DIRECT || MODE == SRC_CONCAT_UP || MODE == SRC_STEM,
+    static_assert(MODE == SRC_DIRECT || MODE == SRC_CONCAT_UP || MODE == SRC_STEM || MODE == SRC_DIRECT_X2,
                   "pooling is fused into the producer");
+    // precision "bf16x2" (SRC_DIRECT_X2): two-piece activations and weights, three virtual planes per real plane
+    constexpr bool X2 = MODE == SRC_DIRECT_X2;
+    constexpr bool DIRECT = MODE == SRC_DIRECT || X2;
+    static_assert(!X2 || sizeof(T) == 2, "two-piece operands are bf16");
     static_assert(MODE != SRC_STEM || (sizeof(T) == 2 && BN == 64), "fused stem: bf16, 64 couts");
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -895,9 +901,11 @@ __global__ __launch_bounds__(256, conv_occupancy(BN, TH, TW)) void conv3x3_mfma_
     for (int kx = 0; kx < 3; ++kx)
         b_off[kx] = (wp * ROWS_W * TWP + kx + l15) * 64 + ((lc ^ swz(kx + l15)) << 4);
 
-    const int nplanes_all = (a.C0 + a.C1) / PL;
+    const int nplanes_real = (a.C0 + a.C1) / PL;
+    // X2: virtual plane v = 3 * real plane + j, j = 0: (xh, wh), 1: (xh, wl) on the SAME in-tile, 2: (xl, wh)
+    const int nplanes_all = X2 ? 3 * nplanes_real : nplanes_real;
     const int p0 = a.C0 / PL;
-    // this workgroup's K slice: planes [pbeg, pend)
+    // this workgroup's K slice: (virtual) planes [pbeg, pend)
     const int pbeg = split * nplanes_all / ksplit, pend = (split + 1) * nplanes_all / ksplit;
     const int nsteps = (pend - pbeg) * 3;
     const char* wbase = (const char*)a.wgt + (size_t)ct * BN * 64;
@@ -911,7 +919,12 @@ __global__ __launch_bounds__(256, conv_occupancy(BN, TH, TW)) void conv3x3_mfma_
     static_assert(BN % 16 == 0, "a weight piece must not straddle two taps");
     const unsigned w_lane_off = (unsigned)((lane >> 2) * 64 + (((lane & 3) ^ swz(lane >> 2)) << 4));
     auto issue_w = [&](int step) __attribute__((always_inline)) {  // step counts from this slice's start
-        const int lp = step / 3, kx = step - lp * 3, pl = pbeg + lp;
+        const int lp = step / 3, kx = step - lp * 3;
+        int pl = pbeg + lp;
+        if constexpr (X2) {  // weight planes: [wh of every real plane | wl of every real plane]
+            const int real = pl / 3;
+            pl = pl - real * 3 == 1 ? nplanes_real + real : real;
+        }
         const char* wsrc = wbase + ((size_t)(pl * 9 + kx * 3) * a.Cout) * 64;  // packed [plane][kx][ky][cout]
         const unsigned dst = __builtin_amdgcn_readfirstlane(
             lds_w_addr + (unsigned)((step & 1) * Tile::W_STRIDE + wave * NW * 1024));
@@ -932,17 +945,17 @@ __global__ __launch_bounds__(256, conv_occupancy(BN, TH, TW)) void conv3x3_mfma_
     constexpr int NPIECE = THP * TWP / 16;
     static_assert(THP * TWP % 16 == 0, "in-tile must be a whole number of 1-KiB pieces");
     const int aH = a.H, aW = a.W;
-    const char* const dma_src = (const char*)a.src0 + (size_t)b * a.H * a.W * a.C0 * sizeof(T);
+    const char* const dma_src = (const char*)a.src0 + (size_t)b * a.H * a.W * a.C0 * sizeof(T) * (X2 ? 2 : 1);
     // SRC_DIRECT with C1 > 0: planes >= p0 come from a second full-resolution tensor (the upsampled
     // half of a concat input, materialised by upsample_kernel when several cout tiles share it)
-    const char* const dma_src1 = MODE == SRC_DIRECT && a.C1 > 0
-                                     ? (const char*)a.src1 + (size_t)b * a.H * a.W * a.C1 * sizeof(T) : nullptr;
+    const char* const dma_src1 = DIRECT && a.C1 > 0
+                                     ? (const char*)a.src1 + (size_t)b * a.H * a.W * a.C1 * sizeof(T) * (X2 ? 2 : 1) : nullptr;
     // The per-lane source offset of every piece is plane-invariant in the blocked layout.  Where
     // registers allow (the plain 128-cout direct kernels) it is computed once (NPW registers, 32-bit)
     // and a plane's gather costs ~8 instructions per piece; the pooled / concat / head / split-K
     // variants and the 64-cout tiles (12-14 pieces per wave), which are at the 256-VGPR limit,
     // rebuild it per plane from three registers (see pm_* below; hoisting there spills).
-    constexpr bool HOIST = (MODE == SRC_DIRECT && BN == 128 && EPI == EPI_PLAIN);   // (EPI_PLAIN_X2 with it: 3 spilled registers)
+    constexpr bool HOIST = (MODE == SRC_DIRECT && BN == 128 && EPI == EPI_PLAIN);   // (the two-piece epilogue with it: 3 spilled registers)
     // Rolling window of in-tile rows across the three ky taps of a step (24 instead of 36 fragment
     // reads per step): bf16 32-wide tiles.  The fp32 instantiations (4 MFMAs per fragment pair keep
     // more operands in flight) and the 16-wide tiles have no registers to spare for the extra row
@@ -1011,8 +1024,15 @@ __global__ __launch_bounds__(256, conv_occupancy(BN, TH, TW)) void conv3x3_mfma_
     }
     auto gather_plane_dma = [&](int plane) __attribute__((always_inline)) {
         // wave-uniform plane base in SGPRs + the lane's 32-bit offset
-        const char* const base = (MODE == SRC_DIRECT && plane >= p0) ? dma_src1 + (size_t)(plane - p0) * plane_bytes
-                                                                     : dma_src + (size_t)plane * plane_bytes;
+        const char* base;
+        if constexpr (X2) {  // virtual plane -> (real plane, piece): the lo planes follow the hi planes of their tensor
+            const int real = plane / 3, lo = plane - real * 3 == 2;
+            base = real >= p0 ? dma_src1 + (size_t)(real - p0 + (lo ? nplanes_real - p0 : 0)) * plane_bytes
+                              : dma_src + (size_t)(real + (lo ? p0 : 0)) * plane_bytes;
+        } else {
+            base = (MODE == SRC_DIRECT && plane >= p0) ? dma_src1 + (size_t)(plane - p0) * plane_bytes
+                                                       : dma_src + (size_t)plane * plane_bytes;
+        }
         for_pieces([&](int j, bool ok, unsigned off) __attribute__((always_inline)) {
             if (ok) glds16s(base, off, __builtin_amdgcn_readfirstlane(lds_in_addr + (unsigned)j * 1024u));
         });
@@ -1379,7 +1399,7 @@ __global__ __launch_bounds__(256, conv_occupancy(BN, TH, TW)) void conv3x3_mfma_
                 gather_plane_stem(w1);
             }
         }
-        else if (MODE == SRC_DIRECT || plane < p0) gather_plane_dma(plane);
+        else if (DIRECT || plane < p0) gather_plane_dma(plane);
         else gather_plane_up(plane, idle_slot);
     };
 
@@ -1397,7 +1417,11 @@ __global__ __launch_bounds__(256, conv_occupancy(BN, TH, TW)) void conv3x3_mfma_
     STAMP(1);
 
     int step = 0;
+    int vj = X2 ? pbeg % 3 : 0;   // X2: piece combination of the current virtual plane
     for (int plane = pbeg; plane < pend; ++plane) {
+        // X2: the plane after an (xh, wh) plane multiplies the same in-tile by wl - no gather, no boundary
+        const bool gather_next = plane + 1 < pend && !(X2 && vj == 0);
+        if constexpr (X2) vj = vj == 2 ? 0 : vj + 1;
 #pragma unroll
         for (int kx = 0; kx < 3; ++kx, ++step) {
             // W(step) and the in-tile of `plane` are resident.  Stream W(step+1) into the other
@@ -1411,13 +1435,13 @@ __global__ __launch_bounds__(256, conv_occupancy(BN, TH, TW)) void conv3x3_mfma_
             // so a barrier there declares the in-tile dead and the next plane's DMA is issued BEFORE
             // the remaining 64 MFMAs, which cover its round trip (no second in-tile buffer needed).
 #ifndef FIUNET_NO_EARLY_GATHER
-            constexpr bool EARLY_OK = ROLL && MODE == SRC_DIRECT;  // (the concat kernels would spill 6-8 registers)
+            constexpr bool EARLY_OK = ROLL && DIRECT;  // (the concat kernels would spill 6-8 registers)
 #else
             constexpr bool EARLY_OK = false;
 #endif
             bool early = false;
             if constexpr (EARLY_OK)
-                early = kx == 2 && plane + 1 < pend && (MODE == SRC_DIRECT || plane + 1 < p0);
+                early = kx == 2 && gather_next && (DIRECT || plane + 1 < p0);
             if constexpr (ROLL) {
                 uint4 xb[ROWS_W + 2][FR];
                 auto load_row = [&](int i) __attribute__((always_inline)) {
@@ -1480,7 +1504,7 @@ __global__ __launch_bounds__(256, conv_occupancy(BN, TH, TW)) void conv3x3_mfma_
             __builtin_amdgcn_sched_barrier(0);
 #endif
             STAMP(2);
-            if (kx == 2 && plane + 1 < pend && !early) {
+            if (kx == 2 && gather_next && !early) {
                 __syncthreads();  // every wave is done with this plane's in-tile and with W(step)
                 gather_plane(plane + 1, step & 1, false);
                 lds_dma_wait_all();
@@ -1494,7 +1518,7 @@ __global__ __launch_bounds__(256, conv_occupancy(BN, TH, TW)) void conv3x3_mfma_
         }
     }
 
-    conv_epilogue<T, BN, TH, TW, EPI>(a, acc, b, y0, x0, ct, split, wc, wp, l15, lc);
+    conv_epilogue<T, BN, TH, TW, EPI, X2>(a, acc, b, y0, x0, ct, split, wc, wp, l15, lc);
 #ifdef FIUNET_STAMP
     STAMP(5);
     st_sum[0] = st_prev - st_t0;

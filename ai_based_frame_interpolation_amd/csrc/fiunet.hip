@@ -71,7 +71,7 @@ struct ConvWeights {
     int cin = 0, cout = 0;
     void* w_f32 = nullptr;   // packed [cin/16][kx][ky][cout][16] fp32   (conv 0: [9][cin][64])
     void* w_bf16 = nullptr;  // packed [cin/32][kx][ky][cout][32] bf16
-    void* w_x2 = nullptr;    // FIUNET_BF16X2: the same packing over 3 * cin input channels, pieces [wh | wl | wh]
+    void* w_x2 = nullptr;    // FIUNET_BF16X2 (fiunet_prepare_precision): two pieces [wh | wl], each packed like w_bf16
     float* scale = nullptr;
     float* shift = nullptr;
 };
@@ -146,7 +146,7 @@ struct PlanOpts {
     bool keep_all = false, unfused = false, fused_stem = false, fused_head = false, gather_up = false;
     const int* cout = kCoutBil;   // architecture: output channels per conv
     bool convt = false;           // bilinear=False: the upsampled half is a ConvTranspose2d output, always materialised
-    bool x2 = false;              // FIUNET_BF16X2: activations are [hi | hi | lo] bf16 tensors of 3 * C channels
+    bool x2 = false;              // FIUNET_BF16X2: activations are two-piece [hi | lo] bf16 tensors of 2 * C channels
 };
 
 // A concat conv whose output spans several 128-cout tiles would bilinearly interpolate every input
@@ -168,7 +168,7 @@ bool make_plan(int B, int H, int W, int precision, const PlanOpts& o, Plan& p)
     // the kernels address a pixel record inside one image plane with 32 bits: H*W*64 B < 4 GiB.
     // Larger frames go through fiunet_forward_strip band by band.
     if ((long long)H * W >= (1LL << 26)) return false;
-    const size_t es = precision == FIUNET_FP32 ? 4 : (o.x2 ? 6 : 2);   // bytes per activation element
+    const size_t es = precision == FIUNET_FP32 ? 4 : (o.x2 ? 4 : 2);   // bytes per activation element
     p.hs[0] = H; p.ws[0] = W;
     for (int k = 1; k < 5; ++k) { p.hs[k] = p.hs[k - 1] / 2; p.ws[k] = p.ws[k - 1] / 2; }
     struct Buf { size_t bytes; int first, last; size_t* off; };
@@ -230,7 +230,8 @@ struct fiunet_ctx {
     int cf = 1;  // channels per frame
     bool bilinear = true;          // false: ConvTranspose2d decoder (unet.py:42-44)
     const int* cout = kCoutBil;    // output channels per conv of this architecture
-    struct { int cin = 0, cout = 0; void* w_f32 = nullptr; void* w_bf16 = nullptr; float* bias = nullptr; } convt[4];
+    struct { int cin = 0, cout = 0; void* w_f32 = nullptr; void* w_bf16 = nullptr; void* w_x2 = nullptr; float* bias = nullptr; } convt[4];
+    bool x2_ready = false;         // the two-piece weight copies exist (fiunet_prepare_precision(FIUNET_BF16X2))
     unsigned flags = 0;
     bool loaded = false;
     ConvWeights conv[NCONV];
@@ -269,6 +270,7 @@ void free_weights(fiunet_ctx* ctx)
     for (void* p : ctx->owned) (void)hipFree(p);
     ctx->owned.clear();
     ctx->loaded = false;
+    ctx->x2_ready = false;
 }
 
 thread_local std::string* g_name_out = nullptr;  // where the next conv launch reports its kernel
@@ -346,10 +348,10 @@ inline unsigned grid_for(size_t n);
 template <typename T, int BN, int TH, int TW, int MODE, int EPI>
 int launch_conv_maybe_split(ConvArgs a, hipStream_t s)
 {
-    constexpr bool X2 = EPI == EPI_PLAIN_X2 || EPI == EPI_POOL_X2;   // precision bf16x2: two-piece output
-    if constexpr (MODE != SRC_STEM && (EPI == EPI_PLAIN || EPI == EPI_POOL || X2)) {
+    constexpr bool X2 = MODE == SRC_DIRECT_X2;   // precision bf16x2: two-piece operands and output, 3 virtual planes per plane
+    if constexpr (MODE != SRC_STEM && (EPI == EPI_PLAIN || EPI == EPI_POOL)) {
         const long long nblk = (long long)a.B * ((a.W + TW - 1) / TW) * ((a.H + TH - 1) / TH) * (a.Cout / BN);
-        const int nplanes = (a.C0 + a.C1) / Elem<T>::PL;
+        const int nplanes = (a.C0 + a.C1) / Elem<T>::PL * (X2 ? 3 : 1);
         int ksplit = (int)std::min<long long>(std::min(nplanes / 2, 16), (256 + nblk - 1) / nblk);
         while (ksplit > 1 && (size_t)ksplit * a.B * a.H * a.W * a.Cout * 4 > kSlabBytes) --ksplit;
         // Fewer workgroups than CUs: cut K as well.  The cut changes the fp32 summation order, so it
@@ -368,13 +370,13 @@ int launch_conv_maybe_split(ConvArgs a, hipStream_t s)
             hipLaunchKernelGGL((splitk_finalize_kernel<T>), dim3(grid_for(n)), dim3(256), 0, s, a.kslab,
                                ksplit, (const float*)nullptr, a.shift, (T*)a.dst, a.B, a.H, a.W, a.Cout, a.relu, X2 ? 1 : 0);
             HIP_TRY(hipGetLastError());
-            if constexpr (EPI == EPI_POOL_X2) {
+            if constexpr (EPI == EPI_POOL && X2) {
                 const size_t np2 = (size_t)a.B * (a.Cout / 32) * (a.H / 2) * (a.W / 2) * 4;
                 hipLaunchKernelGGL(x2_maxpool2_kernel, dim3(grid_for(np2)), dim3(256), 0, s, (const char*)a.dst,
                                    (char*)a.pool_dst, a.B, a.H, a.W, a.Cout);
                 HIP_TRY(hipGetLastError());
             }
-            if constexpr (EPI == EPI_POOL) {
+            if constexpr (EPI == EPI_POOL && !X2) {
                 const size_t np = (size_t)a.B * (a.H / 2) * (a.W / 2) * (a.Cout * sizeof(T) / 16);
                 hipLaunchKernelGGL((maxpool2_kernel<T>), dim3(grid_for(np)), dim3(256), 0, s,
                                    (const T*)a.dst, (T*)a.pool_dst, a.B, a.H, a.W, a.Cout);
@@ -420,7 +422,7 @@ PlanOpts plan_opts(const fiunet_ctx* ctx, int H, int W, int precision)
     o.cout = ctx->cout;
     o.convt = !ctx->bilinear;
     o.x2 = precision == FIUNET_BF16X2;
-    if (o.x2) { o.fused_stem = false; o.fused_head = true; o.keep_all = o.unfused = o.gather_up = false; }
+    if (o.x2) { o.fused_stem = false; o.fused_head = !o.keep_all; o.unfused = o.gather_up = false; }
     return o;
 }
 
@@ -450,9 +452,11 @@ template <typename T> int launch_conv(const ConvArgs& a, int mode, int epi, hipS
     if (mode == SRC_DIRECT && epi == EPI_HEAD) return launch_conv_shape<T, SRC_DIRECT, EPI_HEAD>(a, s);
     if (mode == SRC_DIRECT && epi == EPI_HEAD3) return launch_conv_shape<T, SRC_DIRECT, EPI_HEAD3>(a, s);
     if (mode == SRC_DIRECT && epi == EPI_POOL) return launch_conv_shape<T, SRC_DIRECT, EPI_POOL>(a, s);
-    if constexpr (sizeof(T) == 2) {   // FIUNET_BF16X2: splitting epilogues
-        if (mode == SRC_DIRECT && epi == EPI_PLAIN_X2) return launch_conv_shape<T, SRC_DIRECT, EPI_PLAIN_X2>(a, s);
-        if (mode == SRC_DIRECT && epi == EPI_POOL_X2) return launch_conv_shape<T, SRC_DIRECT, EPI_POOL_X2>(a, s);
+    if constexpr (sizeof(T) == 2) {   // FIUNET_BF16X2: two-piece operands
+        if (mode == SRC_DIRECT_X2 && epi == EPI_PLAIN) return launch_conv_shape<T, SRC_DIRECT_X2, EPI_PLAIN>(a, s);
+        if (mode == SRC_DIRECT_X2 && epi == EPI_POOL) return launch_conv_shape<T, SRC_DIRECT_X2, EPI_POOL>(a, s);
+        if (mode == SRC_DIRECT_X2 && epi == EPI_HEAD) return launch_conv_shape<T, SRC_DIRECT_X2, EPI_HEAD>(a, s);
+        if (mode == SRC_DIRECT_X2 && epi == EPI_HEAD3) return launch_conv_shape<T, SRC_DIRECT_X2, EPI_HEAD3>(a, s);
     }
     if constexpr (sizeof(T) == 2) {
         if (mode == SRC_STEM && epi == EPI_POOL && a.Cout == 64)  // 16x32 tiles only (LDS budget)
@@ -657,17 +661,21 @@ int forward_impl(fiunet_ctx* ctx, const float* f1, const float* f2, float* out, 
     return FIUNET_OK;
 }
 
-// FIUNET_BF16X2: the fp32 contract on the bf16 pipe (include/fiunet.h).  Activations are two-piece tensors of 3 * C bf16
-// channels [hi | hi | lo]; every conv is the plain bf16 direct kernel over them with the [wh | wl | wh] weights and a
-// splitting epilogue (EPI_PLAIN_X2 / EPI_POOL_X2), the stem is the exact-fp32 kernel with a splitting epilogue, the
-// upsampled halves are always materialised (x2_upsample_kernel: fp32 interpolation of hi + lo), the head is the usual
-// fused fp32 reduction.  Small problems K-split like the other precisions (splitk_finalize_kernel writes the two pieces,
-// x2_maxpool2_kernel the pooled copy); no ablation / read-back options.
+// FIUNET_BF16X2: the fp32 contract on the bf16 pipe (include/fiunet.h).  Activations are two-piece bf16 tensors
+// [hi planes | lo planes] (4 B per element), weights [wh | wl]; every conv is the bf16 direct kernel in mode
+// SRC_DIRECT_X2 (three virtual planes per real plane: (xh, wh), (xh, wl) on the same in-tile, (xl, wh)), the stem is the
+// exact-fp32 kernel with a splitting epilogue, the upsampled halves are always materialised (x2_upsample_kernel: fp32
+// interpolation of hi + lo; bilinear=False: convt2x2_kernel<bf16, X2>), the head is the usual fused fp32 reduction.
+// Small problems K-split like the other precisions (splitk_finalize_kernel writes the two pieces, x2_maxpool2_kernel
+// the pooled copy).  FIUNET_OPT_KEEP_ALL keeps every activation for the read-back; no ablation path.
 int forward_x2(fiunet_ctx* ctx, const float* f1, const float* f2, float* out, int B, int H, int W, char* ws,
                const Plan& p, hipStream_t s, int y_origin, int Hg, uint8_t* out_u8)
 {
     using T = __bf16;
-    if (!ctx->bilinear) return fail(FIUNET_ERR_UNSUPPORTED, "bf16x2: bilinear=True only");
+    if (!ctx->x2_ready)
+        return fail(FIUNET_ERR_NOT_LOADED, "precision bf16x2: call fiunet_prepare_precision(ctx, FIUNET_BF16X2) after "
+                                           "fiunet_load_weights (it builds the two-piece weight copies)");
+    const bool keep_all = ctx->flags & FIUNET_OPT_KEEP_ALL;
     int hg[5];
     hg[0] = Hg;
     for (int l = 1; l < 5; ++l) hg[l] = hg[l - 1] / 2;
@@ -715,12 +723,12 @@ int forward_x2(fiunet_ctx* ctx, const float* f1, const float* f2, float* out, in
         a.kslab = i == NCONV - 1 ? nullptr : (float*)(ws + p.slab_off);   // small problems: K-split like the other paths
         a.dst = act(i);
         a.src0 = act(kSrc0[i]);
-        a.C0 = 3 * ctx->cout[kSrc0[i]];
+        a.C0 = ctx->cout[kSrc0[i]];                // REAL channels: the kernel knows both pieces of a tensor
         if (kMode[i] == SRC_POOL) {
             a.src0 = ws + p.pool_off[lv - 1];
         } else if (kMode[i] == SRC_CONCAT_UP) {
             a.src1 = act(kSrc1[i]);
-            a.C1 = ctx->cout[kSrc1[i]];            // REAL channels for the upsample kernel; tripled below
+            a.C1 = ctx->cout[kSrc1[i]];
             a.lowH = p.hs[lv + 1]; a.lowW = p.ws[lv + 1];
             a.lowHg = hg[lv + 1];
             a.upOffY = y_origin >> lv;
@@ -730,25 +738,43 @@ int forward_x2(fiunet_ctx* ctx, const float* f1, const float* f2, float* out, in
             a.sy = 2 * a.lowHg > 1 ? (float)(a.lowHg - 1) / (float)(2 * a.lowHg - 1) : 0.f;
             a.sx = 2 * a.lowW > 1 ? (float)(a.lowW - 1) / (float)(2 * a.lowW - 1) : 0.f;
             char* up = ws + p.up_off[i];
-            const size_t n = (size_t)B * (a.C1 / 32) * a.H * a.W * 4;
-            hipLaunchKernelGGL(x2_upsample_kernel, dim3(grid_for(n)), dim3(256), 0, s, a, up);
-            HIP_TRY(hipGetLastError());
+            if (ctx->bilinear) {
+                const dim3 grid((unsigned)((a.W * 4 + 255) / 256), (unsigned)((a.H + UPS_ROWS - 1) / UPS_ROWS),
+                                (unsigned)(B * (a.C1 / 32)));
+                if (grid.y > 65535u || grid.z > 65535u) return fail(FIUNET_ERR_INVALID_ARG, "upsample grid too large");
+                hipLaunchKernelGGL(x2_upsample_kernel, grid, dim3(256), 0, s, a, up);
+                HIP_TRY(hipGetLastError());
+            } else {   // bilinear=False (unet.py:42-44): ConvTranspose2d(C, C / 2, 2, 2) + F.pad on two-piece operands
+                const auto& ct = ctx->convt[(i - 10) / 2];
+                ConvTArgs c;
+                std::memset(&c, 0, sizeof(c));
+                c.low = a.src1; c.wgt = ct.w_x2; c.bias = ct.bias; c.dst = up;
+                c.B = B; c.H = a.H; c.W = a.W; c.lowH = a.lowH; c.lowW = a.lowW; c.Cin = ct.cin; c.Cout = ct.cout;
+                c.padT = a.padT; c.padL = a.padL; c.upOffY = a.upOffY; c.lowOffY = a.lowOffY; c.lowHg = a.lowHg;
+                if (a.C1 != ct.cin) return fail(FIUNET_ERR_INVALID_ARG, "internal: transposed-conv channel plan mismatch");
+                if (y_origin != 0 || Hg != H || a.H != 2 * a.lowH || a.W != 2 * a.lowW)   // F.pad rows / columns (and a band's edges)
+                    HIP_TRY(hipMemsetAsync(up, 0, (size_t)B * a.H * a.W * ct.cout * 4, s));
+                const long long units = (long long)B * a.lowH * ((a.lowW + 31) / 32) * (ct.cout / 64);
+                hipLaunchKernelGGL((convt2x2_kernel<T, true>), dim3((unsigned)std::min<long long>((units + 3) / 4, 256 * 16)),
+                                   dim3(256), 0, s, c);
+                HIP_TRY(hipGetLastError());
+                a.C1 = ct.cout;
+            }
             a.src1 = up;
-            a.C1 = 3 * a.C1;
         }
-        if (a.C0 + a.C1 != 3 * cw.cin) return fail(FIUNET_ERR_INVALID_ARG, "internal: bf16x2 channel plan mismatch");
-        int epi = EPI_PLAIN_X2;
+        if (a.C0 + a.C1 != cw.cin) return fail(FIUNET_ERR_INVALID_ARG, "internal: bf16x2 channel plan mismatch");
+        int epi = EPI_PLAIN;
         if (kPoolOut[i] >= 0) {
-            epi = EPI_POOL_X2;
+            epi = EPI_POOL;
             a.pool_dst = ws + p.pool_off[kPoolOut[i]];
         }
         if (i == NCONV - 1) {
             epi = ctx->cf == 1 ? EPI_HEAD : EPI_HEAD3;
             a.head_w = ctx->head_w; a.head_b = ctx->head_b; a.head_out = out; a.head_out_u8 = out_u8; a.head_nc = ctx->cf;
-            a.dst = nullptr;
+            if (!keep_all) a.dst = nullptr;
         }
         g_name_out = ev ? &ctx->layer_name[i] : nullptr;
-        const int rc = launch_conv<T>(a, SRC_DIRECT, epi, s);
+        const int rc = launch_conv<T>(a, SRC_DIRECT_X2, epi, s);
         g_name_out = nullptr;
         if (rc != FIUNET_OK) return rc;
         if (ev) {
@@ -909,33 +935,6 @@ int fiunet_load_weights(fiunet_ctx* ctx, int n, const char* const* names,
         }
         if ((rc = dev_upload(ctx, p32.data(), nel * 4, &cw.w_f32))) return rc;
         if ((rc = dev_upload(ctx, p16.data(), nel * 2, &cw.w_bf16))) return rc;
-        if (ctx->bilinear) {
-            // FIUNET_BF16X2: the same packing over 3 * cin input channels.  The activations arrive as blocks
-            // [hi | hi | lo] per source tensor (a concat conv: the skip tensor's three blocks, then the upsampled
-            // tensor's), the weights go [wh | wl | wh] against them: wh*xh + wl*xh + wh*xl.  w * bn_scale = wh + wl to
-            // 2^-17 relative (both pieces rounded to nearest).
-            const int c0 = kMode[i] == SRC_CONCAT_UP ? kCout[kSrc0[i]] : cin;   // channels of the first source
-            const int cin3 = 3 * cin;
-            std::vector<uint16_t> px((size_t)cout * cin3 * 9);
-            for (int R = 0; R < cout; ++R) {
-                const int co16 = bf16_row_to_cout(R);
-                for (int k = 0; k < cin3; ++k) {
-                    int ci, piece;   // real input channel, weight piece (0 = hi, 1 = lo)
-                    if (k < 3 * c0) { ci = k % c0; piece = (k / c0) == 1; }
-                    else { const int kk = k - 3 * c0, c1 = cin - c0; ci = c0 + kk % c1; piece = (kk / c1) == 1; }
-                    for (int t = 0; t < 9; ++t) {
-                        const int slot = (t % 3) * 3 + t / 3;
-                        const float wv = w[((size_t)co16 * cin + ci) * 9 + t] * sc[co16];
-                        const uint16_t hi = f32_to_bf16_rne(wv);
-                        uint32_t hb = (uint32_t)hi << 16;
-                        float hf;
-                        std::memcpy(&hf, &hb, 4);
-                        px[(((size_t)(k / 32) * 9 + slot) * cout + R) * 32 + (k % 32)] = piece ? f32_to_bf16_rne(wv - hf) : hi;
-                    }
-                }
-            }
-            if ((rc = dev_upload(ctx, px.data(), px.size() * 2, &cw.w_x2))) return rc;
-        }
     }
     if (!ctx->bilinear) {
         // ConvTranspose2d weights [Cin][Cout = Cin / 2][2][2] + bias (unet.py:43): packed per tap t = dy*2 + dx as
@@ -991,11 +990,41 @@ int fiunet_load_weights(fiunet_ctx* ctx, int n, const char* const* names,
     return FIUNET_OK;
 }
 
+int fiunet_prepare_precision(fiunet_ctx* ctx, int precision)
+{
+    if (!ctx) return fail(FIUNET_ERR_INVALID_ARG, "ctx is NULL");
+    if (precision != FIUNET_FP32 && precision != FIUNET_BF16 && precision != FIUNET_BF16X2)
+        return fail(FIUNET_ERR_INVALID_ARG, "bad precision");
+    if (!ctx->loaded) return fail(FIUNET_ERR_NOT_LOADED, "fiunet_prepare_precision before fiunet_load_weights");
+    if (precision != FIUNET_BF16X2 || ctx->x2_ready) return FIUNET_OK;   // fp32 / bf16 copies are made by the load
+    HIP_TRY(hipSetDevice(ctx->device));
+    // two-piece weights [wh | wl], packed on the device from the fp32 copy (BatchNorm scale folded in): ~69 MB more
+    auto pack = [&](const void* w32, int cin, int cout, int convt, void** out) -> int {
+        const size_t n = (size_t)2 * cin * (convt ? 4 : 9) * cout;
+        void* d = nullptr;
+        HIP_TRY(hipMalloc(&d, n * 2));
+        ctx->owned.push_back(d);
+        hipLaunchKernelGGL(x2_pack_weights_kernel, dim3(grid_for(n)), dim3(256), 0, 0, (const float*)w32,
+                           (unsigned short*)d, cin, cout, convt);
+        HIP_TRY(hipGetLastError());
+        *out = d;
+        return FIUNET_OK;
+    };
+    int rc;
+    for (int i = 1; i < NCONV; ++i)
+        if ((rc = pack(ctx->conv[i].w_f32, ctx->conv[i].cin, ctx->conv[i].cout, 0, &ctx->conv[i].w_x2))) return rc;
+    if (!ctx->bilinear)
+        for (int k = 0; k < 4; ++k)
+            if ((rc = pack(ctx->convt[k].w_f32, ctx->convt[k].cin, ctx->convt[k].cout, 1, &ctx->convt[k].w_x2))) return rc;
+    HIP_TRY(hipDeviceSynchronize());
+    ctx->x2_ready = true;
+    return FIUNET_OK;
+}
+
 size_t fiunet_workspace_bytes(const fiunet_ctx* ctx, int B, int H, int W, int precision)
 {
     Plan p;
     if (!ctx || (precision != FIUNET_FP32 && precision != FIUNET_BF16 && precision != FIUNET_BF16X2) ||
-        (precision == FIUNET_BF16X2 && !ctx->bilinear) ||
         !make_plan(B, H, W, precision, plan_opts(ctx, H, W, precision), p)) {
         g_err = "fiunet_workspace_bytes: bad arguments";
         return 0;
@@ -1307,23 +1336,45 @@ int fiunet_profile_read(fiunet_ctx* ctx, int* n_forwards, float* avg_ms, double*
 }
 
 int fiunet_debug_read_activation(fiunet_ctx* ctx, const void* workspace, int B, int H, int W,
-                                 int precision, int tap, float* dst, int out_dims[3], void* stream)
+                                 int precision, int tap, float* dst, size_t dst_capacity, int out_dims[3], void* stream)
 {
-    if (!ctx || !workspace || !dst || tap < 0 || tap >= NCONV)
+    if (!ctx || tap < 0 || tap >= NCONV + 4 || (dst && !workspace))
         return fail(FIUNET_ERR_INVALID_ARG, "bad argument");
+    if (precision != FIUNET_FP32 && precision != FIUNET_BF16 && precision != FIUNET_BF16X2)
+        return fail(FIUNET_ERR_INVALID_ARG, "bad precision");
     Plan p;
-    if (precision == FIUNET_BF16X2)
-        return fail(FIUNET_ERR_UNSUPPORTED, "read-back is not available in the bf16x2 precision (two-piece activations)");
-    if (!(ctx->flags & FIUNET_OPT_KEEP_ALL))
+    if (dst && !(ctx->flags & FIUNET_OPT_KEEP_ALL))
         return fail(FIUNET_ERR_INVALID_ARG, "read-back needs FIUNET_OPT_KEEP_ALL set for the forward: without it "
                                             "activations share workspace bytes and are overwritten");
     if (!make_plan(B, H, W, precision, plan_opts(ctx, H, W, precision), p))
         return fail(FIUNET_ERR_BAD_SHAPE, "bad shape");
-    const int C = ctx->cout[tap], h = p.hs[kLevel[tap]], w = p.ws[kLevel[tap]];
+    // channels of THIS architecture (the ConvTranspose2d decoder is wider than the bilinear one at taps 8, 9, 11, 13, 15)
+    int C, lv;
+    size_t off;
+    if (tap < NCONV) {
+        C = ctx->cout[tap]; lv = kLevel[tap]; off = p.act_off[tap];
+    } else {   // taps 18..21: `self.up(x1)` + F.pad of up1..up4 (unet.py:47-53) where it is a tensor of its own
+        const int i = 10 + 2 * (tap - NCONV);
+        lv = kLevel[i];
+        const PlanOpts po = plan_opts(ctx, H, W, precision);
+        if (!materialise_up(i, precision, po.unfused || po.gather_up, (long long)B * p.hs[lv] * p.ws[lv], ctx->cout, po.convt))
+            return fail(FIUNET_ERR_UNSUPPORTED, "read-back: the upsampled half of this stage is interpolated inside the "
+                                                "conv's gather in this configuration, never stored");
+        C = po.convt ? ctx->cout[kSrc1[i]] / 2 : ctx->cout[kSrc1[i]];
+        off = p.up_off[i];
+    }
+    const int h = p.hs[lv], w = p.ws[lv];
     if (out_dims) { out_dims[0] = C; out_dims[1] = h; out_dims[2] = w; }
+    if (!dst) return FIUNET_OK;   // dims-only query
     const size_t n = (size_t)B * C * h * w;
-    const char* src = (const char*)workspace + p.act_off[tap];
-    if (precision == FIUNET_BF16)
+    if (dst_capacity < n)
+        return fail(FIUNET_ERR_INVALID_ARG, "read-back: dst holds " + std::to_string(dst_capacity) + " floats, tap " +
+                                            std::to_string(tap) + " has " + std::to_string(n));
+    const char* src = (const char*)workspace + off;
+    if (precision == FIUNET_BF16X2)
+        hipLaunchKernelGGL(x2_to_nchw_f32_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream,
+                           (const __bf16*)src, dst, B, C, h, w);
+    else if (precision == FIUNET_BF16)
         hipLaunchKernelGGL((nhwc_to_nchw_f32_kernel<__bf16>), dim3(grid_for(n)), dim3(256), 0,
                            (hipStream_t)stream, (const __bf16*)src, dst, B, C, h, w);
     else

@@ -16,7 +16,8 @@
 
 namespace fiunet {
 
-// ---- "bf16x2" precision: helpers around the two-piece [hi | hi | lo] activation layout (conv3x3_mfma.hip.h, EPI_*_X2)
+// ---- "bf16x2" precision: helpers around the two-piece activation layout [hi planes | lo planes] of one image
+//      (conv3x3_mfma.hip.h, SRC_DIRECT_X2); block_bytes = bytes from a hi record to its lo record = C/32 planes
 __device__ __forceinline__ void x2_split_store(char* o, size_t block_bytes, const float (&v)[8])
 {
     unsigned h[4], l[4];
@@ -25,16 +26,14 @@ __device__ __forceinline__ void x2_split_store(char* o, size_t block_bytes, cons
         h[i] = pack_bf16x2_pk(v[2 * i], v[2 * i + 1]);
         l[i] = pack_bf16x2_pk(v[2 * i] - __uint_as_float(h[i] << 16), v[2 * i + 1] - __uint_as_float(h[i] & 0xffff0000u));
     }
-    const uint4 hv = make_uint4(h[0], h[1], h[2], h[3]);
-    *reinterpret_cast<uint4*>(o) = hv;
-    *reinterpret_cast<uint4*>(o + block_bytes) = hv;
-    *reinterpret_cast<uint4*>(o + 2 * block_bytes) = make_uint4(l[0], l[1], l[2], l[3]);
+    *reinterpret_cast<uint4*>(o) = make_uint4(h[0], h[1], h[2], h[3]);
+    *reinterpret_cast<uint4*>(o + block_bytes) = make_uint4(l[0], l[1], l[2], l[3]);
 }
 __device__ __forceinline__ void x2_load(const char* p, size_t block_bytes, float (&v)[8])
 {
     float hi[8], lo[8];
     chunk_unpack<__bf16>(ldg16(p), hi);
-    chunk_unpack<__bf16>(ldg16(p + 2 * block_bytes), lo);
+    chunk_unpack<__bf16>(ldg16(p + block_bytes), lo);
 #pragma unroll
     for (int i = 0; i < 8; ++i) v[i] = hi[i] + lo[i];   // exact: the two pieces do not overlap
 }
@@ -46,8 +45,8 @@ __device__ __forceinline__ void x2_load(const char* p, size_t block_bytes, float
 // The A rows are permuted so that lane (pixel, q) ends up with couts 16q..16q+15: its epilogue
 // is 32 (bf16) / 64 (fp32) contiguous bytes and the 4 lanes of a pixel cover its whole 64-channel
 // NHWC record.  K = 18 (gray) or 54 (RGB) is zero-padded to a multiple of 4.
-// X2 (precision bf16x2): the exact-fp32 result is split into two bf16 pieces right here and written as the [hi | hi | lo]
-// tensor of 3 * 64 channels (T = bf16 is then only the element type of `dst`; no dither: this is the fp32-contract path).
+// X2 (precision bf16x2): the exact-fp32 result is split into two bf16 pieces right here and written as the [hi | lo]
+// tensor of 2 * 64 channels (T = bf16 is then only the element type of `dst`; no dither: this is the fp32-contract path).
 template <typename T, int CF, bool X2 = false>
 __global__ __launch_bounds__(256) void conv3x3_first_kernel(
     const float* __restrict__ f1, const float* __restrict__ f2, const float* __restrict__ w,
@@ -144,7 +143,7 @@ __global__ __launch_bounds__(256) void conv3x3_first_kernel(
             if constexpr (X2) {
                 if (x < W) {   // couts lc*16 .. +15 = two 16-B chunks of plane lc / 2; blocks of 2 planes per image
                     const size_t blk = (size_t)2 * H * W * 64;
-                    char* op = (char*)dst + (size_t)b * 3 * blk + blk_off(lc >> 1, y, x, H, W) + (size_t)(lc & 1) * 32;
+                    char* op = (char*)dst + (size_t)b * 2 * blk + blk_off(lc >> 1, y, x, H, W) + (size_t)(lc & 1) * 32;
                     float c0[8], c1[8];
 #pragma unroll
                     for (int c = 0; c < 8; ++c) { c0[c] = o[c]; c1[c] = o[8 + c]; }
@@ -312,9 +311,12 @@ struct ConvTArgs {
     int upOffY, lowOffY, lowHg;   // row band of a taller image (fiunet_forward_strip); un-tiled: 0, 0, lowH
 };
 
-template <typename T>
+// X2 (precision bf16x2): `low` and `dst` are two-piece tensors [hi planes | lo planes], the weights [wh | wl] (both
+// pieces [4][Cin/32][Cout][32]); a product is wh*xh + wl*xh + wh*xl, the bias is added in fp32 and the sum split again.
+template <typename T, bool X2 = false>
 __global__ __launch_bounds__(256) void convt2x2_kernel(const ConvTArgs a)
 {
+    static_assert(!X2 || sizeof(T) == 2, "two-piece operands are bf16");
     constexpr int PL = Elem<T>::PL;
     constexpr int NPX = 2;   // 16-pixel fragments per wave: every weight fragment is used for 32 pixels
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -331,7 +333,7 @@ __global__ __launch_bounds__(256) void convt2x2_kernel(const ConvTArgs a)
 #pragma unroll
         for (int f = 0; f < NPX; ++f) {
             const int xl = min(tx * 16 * NPX + f * 16 + l15, a.lowW - 1);
-            bsrc[f] = (const char*)a.low + (size_t)b * nplanes * low_plane + ((size_t)y * a.lowW + xl) * 64 + lc * 16;
+            bsrc[f] = (const char*)a.low + (size_t)b * nplanes * low_plane * (X2 ? 2 : 1) + ((size_t)y * a.lowW + xl) * 64 + lc * 16;
         }
         const char* wsrc = (const char*)a.wgt + ((size_t)(cg * 64 + l15)) * 64 + lc * 16;
         f32x4 acc[4][4][NPX];
@@ -341,18 +343,30 @@ __global__ __launch_bounds__(256) void convt2x2_kernel(const ConvTArgs a)
             for (int ct = 0; ct < 4; ++ct)
 #pragma unroll
                 for (int f = 0; f < NPX; ++f) acc[t][ct][f] = f32x4{0.f, 0.f, 0.f, 0.f};
+        const size_t wpiece = (size_t)4 * nplanes * a.Cout * 64;   // X2: bytes from wh to wl
         for (int p = 0; p < nplanes; ++p) {
-            uint4 xb[NPX];
+            uint4 xb[NPX], xl[X2 ? NPX : 1];
 #pragma unroll
-            for (int f = 0; f < NPX; ++f) xb[f] = *reinterpret_cast<const uint4*>(bsrc[f] + (size_t)p * low_plane);
+            for (int f = 0; f < NPX; ++f) {
+                xb[f] = *reinterpret_cast<const uint4*>(bsrc[f] + (size_t)p * low_plane);
+                if constexpr (X2) xl[f] = *reinterpret_cast<const uint4*>(bsrc[f] + (size_t)(nplanes + p) * low_plane);
+            }
 #pragma unroll
             for (int t = 0; t < 4; ++t)
 #pragma unroll
                 for (int ct = 0; ct < 4; ++ct) {
-                    const uint4 wa = *reinterpret_cast<const uint4*>(
-                        wsrc + (((size_t)t * nplanes + p) * a.Cout + ct * 16) * 64);
+                    const char* wp = wsrc + (((size_t)t * nplanes + p) * a.Cout + ct * 16) * 64;
+                    const uint4 wa = *reinterpret_cast<const uint4*>(wp);
 #pragma unroll
                     for (int f = 0; f < NPX; ++f) mma_chunk<T>(acc[t][ct][f], wa, xb[f]);
+                    if constexpr (X2) {
+                        const uint4 wl = *reinterpret_cast<const uint4*>(wp + wpiece);
+#pragma unroll
+                        for (int f = 0; f < NPX; ++f) {
+                            mma_chunk<T>(acc[t][ct][f], wl, xb[f]);
+                            mma_chunk<T>(acc[t][ct][f], wa, xl[f]);
+                        }
+                    }
                 }
         }
         // global row of this low-res row, and where its two output rows land in this band
@@ -371,9 +385,15 @@ __global__ __launch_bounds__(256) void convt2x2_kernel(const ConvTArgs a)
                     const float4 bi = *reinterpret_cast<const float4*>(a.bias + co);
                     const f32x4 q = acc[t][ct][f];
                     const float v[4] = {q[0] + bi.x, q[1] + bi.y, q[2] + bi.z, q[3] + bi.w};
-                    char* op = (char*)a.dst + (size_t)b * (a.Cout / PL) * out_plane + blk_off(co / PL, Y, X, a.H, a.W) +
+                    char* op = (char*)a.dst + (size_t)b * (a.Cout / PL) * out_plane * (X2 ? 2 : 1) + blk_off(co / PL, Y, X, a.H, a.W) +
                                (size_t)(co % PL) * sizeof(T);
-                    if constexpr (sizeof(T) == 2)
+                    if constexpr (X2) {
+                        const unsigned h0 = pack_bf16x2_pk(v[0], v[1]), h1 = pack_bf16x2_pk(v[2], v[3]);
+                        *reinterpret_cast<uint2*>(op) = make_uint2(h0, h1);
+                        *reinterpret_cast<uint2*>(op + (size_t)(a.Cout / PL) * out_plane) = make_uint2(
+                            pack_bf16x2_pk(v[0] - __uint_as_float(h0 << 16), v[1] - __uint_as_float(h0 & 0xffff0000u)),
+                            pack_bf16x2_pk(v[2] - __uint_as_float(h1 << 16), v[3] - __uint_as_float(h1 & 0xffff0000u)));
+                    } else if constexpr (sizeof(T) == 2)
                         *reinterpret_cast<uint2*>(op) = make_uint2(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]));
                     else
                         *reinterpret_cast<float4*>(op) = make_float4(v[0], v[1], v[2], v[3]);
@@ -478,7 +498,7 @@ __global__ __launch_bounds__(256) void upsample_kernel(const ConvArgs a, T* __re
 }
 
 // MaxPool2d(2) of a two-piece tensor (the K-split path of small problems; the un-split convs pool in their epilogue):
-// max of the four fp32 values hi + lo, split again.  src [B][3 * C/32][H][W][32] -> dst [B][3 * C/32][H/2][W/2][32].
+// max of the four fp32 values hi + lo, split again.  src [B][2 * C/32][H][W][32] -> dst [B][2 * C/32][H/2][W/2][32].
 __global__ __launch_bounds__(256) void x2_maxpool2_kernel(const char* __restrict__ src, char* __restrict__ dst, int B, int H, int W, int C)
 {
     const int np = C / 32, Ho = H / 2, Wo = W / 2;
@@ -491,7 +511,7 @@ __global__ __launch_bounds__(256) void x2_maxpool2_kernel(const char* __restrict
         const int x = (int)(r % Wo); r /= Wo;
         const int y = (int)(r % Ho); r /= Ho;
         const int p = (int)(r % np), b = (int)(r / np);
-        const char* base = src + (size_t)b * 3 * blk + ((size_t)p * HW + (size_t)(2 * y) * W + 2 * x) * 64 + ch * 16;
+        const char* base = src + (size_t)b * 2 * blk + ((size_t)p * HW + (size_t)(2 * y) * W + 2 * x) * 64 + ch * 16;
         float a0[8], a1[8], a2[8], a3[8], o[8];
         x2_load(base, blk, a0);
         x2_load(base + 64, blk, a1);
@@ -499,44 +519,71 @@ __global__ __launch_bounds__(256) void x2_maxpool2_kernel(const char* __restrict
         x2_load(base + (size_t)W * 64 + 64, blk, a3);
 #pragma unroll
         for (int k = 0; k < 8; ++k) o[k] = fmaxf(fmaxf(a0[k], a1[k]), fmaxf(a2[k], a3[k]));
-        x2_split_store(dst + (size_t)b * 3 * oblk + ((size_t)p * HWo + (size_t)y * Wo + x) * 64 + ch * 16, oblk, o);
+        x2_split_store(dst + (size_t)b * 2 * oblk + ((size_t)p * HWo + (size_t)y * Wo + x) * 64 + ch * 16, oblk, o);
     }
 }
 
 // Upsample(x2, bilinear, align_corners=True) + F.pad of a two-piece tensor: the fp32 value hi + lo of the four
-// neighbours, aten's association in fp32 (chunk_bilerp's), split again.  a.src1 = low-res [B][3 * C1/32][lowH][lowW][32],
-// dst = [B][3 * C1/32][H][W][32]; a.C1 = the REAL channel count.  One thread per (pixel, 16-B chunk).
+// neighbours, aten's association in fp32 (chunk_bilerp's), split again.  a.src1 = low-res [B][2 * C1/32][lowH][lowW][32],
+// dst = [B][2 * C1/32][H][W][32]; a.C1 = the REAL channel count.  Same work split as upsample_kernel: grid =
+// (chunks of a row / 256, H / UPS_ROWS, B * real planes), a thread owns one (pixel column, 16-B chunk) and walks
+// UPS_ROWS output rows down it, carrying the horizontally interpolated source rows from one output row to the next.
 __global__ __launch_bounds__(256) void x2_upsample_kernel(const ConvArgs a, char* __restrict__ dst)
 {
     const int np = a.C1 / 32;
+    const int i = blockIdx.x * 256 + threadIdx.x;  // (x, 16-B chunk) within the row
+    if (i >= a.W * 4) return;
+    const int b = blockIdx.z / np, plane = blockIdx.z - b * np;
+    const UpAxis ux = up_axis_x(a, i >> 2);
+    const size_t low_row = (size_t)a.lowW * 64;
     const size_t HW = (size_t)a.H * a.W, lHW = (size_t)a.lowH * a.lowW;
-    const size_t total = (size_t)a.B * np * HW * 4;
     const size_t blk = (size_t)np * HW * 64, lblk = (size_t)np * lHW * 64;
-    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
-        const int ch = (int)(i & 3);
-        size_t r = i >> 2;
-        const int x = (int)(r % a.W); r /= a.W;
-        const int y = (int)(r % a.H); r /= a.H;
-        const int p = (int)(r % np), b = (int)(r / np);
-        const UpCoord u = up_coord(a, y, x);
+    const char* const col = (const char*)a.src1 + (size_t)b * 2 * lblk + (size_t)plane * lHW * 64 + (i & 3) * 16;
+    const char* const s0 = col + (size_t)ux.i0 * 64;
+    const char* const s1 = col + (size_t)ux.i1 * 64;
+    char* const out = dst + (size_t)b * 2 * blk + ((size_t)plane * HW * 4 + i) * 16;
+    auto hl = [&](int row, float (&h)[8]) __attribute__((always_inline)) {
+        float va[8], vb[8];
+        x2_load(s0 + (size_t)row * low_row, lblk, va);
+        x2_load(s1 + (size_t)row * low_row, lblk, vb);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) h[k] = fmaf(ux.l, vb[k], __fmul_rn(ux.h, va[k]));
+    };
+    float h0[8], h1[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) h0[k] = h1[k] = 0.f;
+    int c0 = -1, c1 = -1;  // source rows currently held in h0 / h1 (wave-uniform)
+    const int ybeg = blockIdx.y * UPS_ROWS, yend = min(a.H, ybeg + UPS_ROWS);
+    for (int y = ybeg; y < yend; ++y) {
+        const UpAxis uy = up_axis_y(a, y);
         float o[8];
 #pragma unroll
         for (int k = 0; k < 8; ++k) o[k] = 0.f;
-        if (u.ok) {
-            const char* base = (const char*)a.src1 + (size_t)b * 3 * lblk + (size_t)p * lHW * 64 + ch * 16;
-            float v00[8], v01[8], v10[8], v11[8];
-            x2_load(base + ((size_t)u.y0 * a.lowW + u.x0) * 64, lblk, v00);
-            x2_load(base + ((size_t)u.y0 * a.lowW + u.x1) * 64, lblk, v01);
-            x2_load(base + ((size_t)u.y1 * a.lowW + u.x0) * 64, lblk, v10);
-            x2_load(base + ((size_t)u.y1 * a.lowW + u.x1) * 64, lblk, v11);
+        if (uy.ok) {
+            if (uy.i0 != c0) {
+                if (uy.i0 == c1) {
 #pragma unroll
-            for (int k = 0; k < 8; ++k) {
-                const float top = fmaf(u.lx, v01[k], __fmul_rn(u.hx, v00[k]));
-                const float bot = fmaf(u.lx, v11[k], __fmul_rn(u.hx, v10[k]));
-                o[k] = fmaf(u.ly, bot, __fmul_rn(u.hy, top));
+                    for (int k = 0; k < 8; ++k) h0[k] = h1[k];
+                } else {
+                    hl(uy.i0, h0);
+                }
+                c0 = uy.i0;
+            }
+            if (uy.i1 != c1) {
+                if (uy.i1 == c0) {
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) h1[k] = h0[k];
+                } else {
+                    hl(uy.i1, h1);
+                }
+                c1 = uy.i1;
+            }
+            if (ux.ok) {
+#pragma unroll
+                for (int k = 0; k < 8; ++k) o[k] = fmaf(uy.l, h1[k], __fmul_rn(uy.h, h0[k]));
             }
         }
-        x2_split_store(dst + (size_t)b * 3 * blk + ((size_t)p * HW + (size_t)y * a.W + x) * 64 + ch * 16, blk, o);
+        x2_split_store(out + (size_t)y * a.W * 64, blk, o);
     }
 }
 
@@ -581,7 +628,7 @@ __global__ __launch_bounds__(256) void splitk_finalize_kernel(const float* __res
                                                               T* __restrict__ dst, int B, int H, int W,
                                                               int C, int relu, int x2 = 0)
 {
-    // x2 != 0 (precision bf16x2, T = bf16): dst is the two-piece tensor of 3 * C channels [hi | hi | lo]
+    // x2 != 0 (precision bf16x2, T = bf16): dst is the two-piece tensor of 2 * C channels [hi | lo]
     constexpr int NE = Elem<T>::NE, PL = Elem<T>::PL;
     const int cpp = C / NE;  // chunks per pixel
     const size_t npix = (size_t)B * H * W, total = npix * cpp;
@@ -612,7 +659,7 @@ __global__ __launch_bounds__(256) void splitk_finalize_kernel(const float* __res
                 float w8[8];
 #pragma unroll
                 for (int e = 0; e < 8; ++e) w8[e] = v[e];
-                x2_split_store((char*)dst + b * 3 * blk + ((size_t)(c0 / 32) * H * W + r) * 64 + (size_t)(c0 % 32) * 2, blk, w8);
+                x2_split_store((char*)dst + b * 2 * blk + ((size_t)(c0 / 32) * H * W + r) * 64 + (size_t)(c0 % 32) * 2, blk, w8);
                 continue;
             }
         }
@@ -636,6 +683,52 @@ __global__ __launch_bounds__(256) void nhwc_to_nchw_f32_kernel(const T* __restri
         const int b = (int)(p / C);
         constexpr int PL = Elem<T>::PL;
         dst[i] = (float)src[((((size_t)b * (C / PL) + c / PL) * H + y) * W + x) * PL + c % PL];
+    }
+}
+
+// read-back of a two-piece activation (precision bf16x2): hi + lo of [B][2 * C/32][H][W][32] as fp32 NCHW
+__global__ __launch_bounds__(256) void x2_to_nchw_f32_kernel(const __bf16* __restrict__ src, float* __restrict__ dst, int B,
+                                                             int C, int H, int W)
+{
+    const size_t total = (size_t)B * C * H * W;
+    const size_t piece = (size_t)(C / 32) * H * W * 32;   // elements from a hi value to its lo value
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        size_t p = i;
+        const int x = (int)(p % W); p /= W;
+        const int y = (int)(p % H); p /= H;
+        const int c = (int)(p % C);
+        const int b = (int)(p / C);
+        const size_t at = (size_t)b * 2 * piece + ((((size_t)(c / 32)) * H + y) * W + x) * 32 + c % 32;
+        dst[i] = (float)src[at] + (float)src[at + piece];
+    }
+}
+
+// Weights of precision bf16x2, built on the device from the packed fp32 copy (BatchNorm scale already folded in):
+// w32 [cin/16][9 slots][cout][16] (rows in natural cout order) -> out [2 pieces][cin/32][9][cout][32] bf16 with the bf16
+// kernels' row permutation (row R holds cout (R & ~31) + ((R & 15) >> 2) * 8 + ((R >> 4) & 1) * 4 + (R & 3), fiunet.hip
+// bf16_row_to_cout); piece 0 = RNE bf16 of w, piece 1 = RNE bf16 of the remainder (w = wh + wl to 2^-17 relative).
+// taps = 9 (3x3 convs) or 4 (ConvTranspose2d 2x2, w32 [4][cin/16][cout][16] -> out [2][4][cin/32][cout][32], natural rows)
+__global__ __launch_bounds__(256) void x2_pack_weights_kernel(const float* __restrict__ w32, unsigned short* __restrict__ out,
+                                                              int cin, int cout, int convt)
+{
+    const int taps = convt ? 4 : 9;
+    const size_t half = (size_t)cin * taps * cout, total = 2 * half;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        const int piece = i >= half;
+        size_t r = piece ? i - half : i;
+        const int k = (int)(r % 32); r /= 32;
+        const int R = (int)(r % cout); r /= cout;
+        int plane, slot;
+        if (convt) { plane = (int)(r % (cin / 32)); slot = (int)(r / (cin / 32)); }
+        else { slot = (int)(r % 9); plane = (int)(r / 9); }
+        const int ci = plane * 32 + k;
+        const int co = convt ? R : (R & ~31) + ((R & 15) >> 2) * 8 + ((R >> 4) & 1) * 4 + (R & 3);
+        const size_t src = convt ? (((size_t)slot * (cin / 16) + ci / 16) * cout + co) * 16 + ci % 16
+                                 : (((size_t)(ci / 16) * 9 + slot) * cout + co) * 16 + ci % 16;
+        const float w = w32[src];
+        const __bf16 hi = (__bf16)w;
+        const __bf16 v = piece ? (__bf16)(w - (float)hi) : hi;
+        out[i] = __builtin_bit_cast(unsigned short, v);
     }
 }
 

@@ -41,6 +41,9 @@ TAP_NAMES = tuple(
               "unet.up2.conv", "unet.up3.conv", "unet.up4.conv")
     for c in (0, 3))
 
+#: read-back taps 18..21: `self.up(x1)` + F.pad of up1..up4 (unet.py:47-53), where it is stored as a tensor
+UP_TAP_NAMES = ("unet.up1.up", "unet.up2.up", "unet.up3.up", "unet.up4.up")
+
 _PRECISIONS = {"fp32": _native.FP32, "float32": _native.FP32, "bf16x2": _native.BF16X2, "bf16": _native.BF16,
                "bfloat16": _native.BF16}
 
@@ -142,9 +145,10 @@ class FrameInterpolationUNet(nn.Module):
       frame_channels: 1 (grayscale, the reference's 2->1 network) or 3 (RGB 6->3 variant the
                       reference README describes); same kernels.
       precision:      "fp32" (default; exact-fp32 MFMA, |d| <= 1e-3 contract), "bf16" (bf16 storage + MFMA,
-                      fp32 accumulate) or "bf16x2" (round 4: the fp32 contract on the bf16 pipe - activations
+                      fp32 accumulate) or "bf16x2" (the fp32 contract on the bf16 pipe - activations
                       and weights as two bf16 pieces, three MFMAs per product, ~1e-5 relative end to end, about
-                      3x the speed of "fp32"; bilinear=True only).  Env FIUNET_PRECISION overrides.
+                      3x the speed of "fp32"; both decoders).  Env FIUNET_PRECISION is the default when the
+                      argument is None.  The attribute may be reassigned between forwards.
     """
 
     def __init__(self, bilinear: bool = False, frame_channels: int = 1, precision: str | None = None):
@@ -258,6 +262,13 @@ class FrameInterpolationUNet(nn.Module):
             self._ws = torch.empty(nbytes, dtype=torch.uint8, device=device)
         return self._ws
 
+    def _precision_code(self) -> int:
+        """`precision` is a plain attribute and may be reassigned between forwards: validated where it is used."""
+        try:
+            return _PRECISIONS[self.precision]
+        except (KeyError, TypeError):
+            raise ValueError(f"precision must be one of {sorted(_PRECISIONS)}, got {self.precision!r}") from None
+
     def _check_pair(self, frame1, frame2, dtype_ok):
         if frame1.dim() != 4 or frame1.shape != frame2.shape:
             raise RuntimeError(
@@ -284,7 +295,7 @@ class FrameInterpolationUNet(nn.Module):
         f1 = frame1.to(torch.float32).contiguous()
         f2 = frame2.to(torch.float32).contiguous()
         b, _, h, w = f1.shape
-        prec = _PRECISIONS[self.precision]
+        prec = self._precision_code()
         ctx = self._context(f1.device)
         ws = self._workspace(ctx, f1.device, b, h, w, prec)
         out = torch.empty_like(f1)
@@ -302,7 +313,7 @@ class FrameInterpolationUNet(nn.Module):
         self._check_pair(frame1, frame2, (torch.float32,))
         f1, f2 = frame1.contiguous(), frame2.contiguous()
         b, _, h, w = f1.shape
-        prec = _PRECISIONS[self.precision]
+        prec = self._precision_code()
         ctx = self._context(f1.device)
         ws = self._workspace(ctx, f1.device, b, h, w, prec)
         out = torch.empty_like(f1)
@@ -317,7 +328,7 @@ class FrameInterpolationUNet(nn.Module):
         self._check_pair(frame1, frame2, (torch.uint8,))
         f1, f2 = frame1.contiguous(), frame2.contiguous()
         b, _, h, w = f1.shape
-        prec = _PRECISIONS[self.precision]
+        prec = self._precision_code()
         ctx = self._context(f1.device)
         ws = self._workspace(ctx, f1.device, b, h, w, prec, u8=True)
         out = torch.empty_like(f1)
@@ -326,19 +337,27 @@ class FrameInterpolationUNet(nn.Module):
         return out
 
     @torch.no_grad()
-    def debug_activations(self, frame1, frame2, taps=None):
+    def debug_activations(self, frame1, frame2, taps=None, with_up=False):
         """Parity-test hook: run one forward keeping every stage and return
-        ({tap name: fp32 NCHW tensor}, output)."""
+        ({tap name: fp32 NCHW tensor}, output).  with_up: also the four upsampled + padded halves
+        (`unet.up{k}.up`, as F.pad leaves them: unet.py:47-53) where they are stored - always with the
+        ConvTranspose2d decoder and in precision "bf16x2"; a stage that interpolates inside its gather is skipped."""
         saved = self._options
         self._options = saved | _native.OPT_KEEP_ALL
         self._ctx_or_none_set_options()
         try:
             out = self.forward(frame1, frame2)
             b, _, h, w = frame1.shape
-            prec = _PRECISIONS[self.precision]
+            prec = self._precision_code()
             acts = {}
             for t in (range(18) if taps is None else taps):
                 acts[TAP_NAMES[t]] = self._ctx.read_activation(self._ws, b, h, w, prec, t)
+            for k in (range(4) if with_up else ()):
+                try:
+                    acts[UP_TAP_NAMES[k]] = self._ctx.read_activation(self._ws, b, h, w, prec, 18 + k)
+                except RuntimeError as e:
+                    if "status 7" not in str(e):   # FIUNET_ERR_UNSUPPORTED: not stored in this configuration
+                        raise
         finally:
             self._options = saved
             self._ctx.set_options(saved)
@@ -377,7 +396,7 @@ class GraphedForward:
         model._check_pair(self.f1, self.f2, (torch.float32,))
         b, _, h, w = self.f1.shape
         ctx = model._context(dev)              # uploads the weights if they are stale
-        prec = _PRECISIONS[model.precision]
+        prec = model._precision_code()
         nbytes = ctx.workspace_bytes(b, h, w, prec)
         if self.ws is None or self.ws.numel() < nbytes:
             self.ws = None

@@ -546,13 +546,23 @@ def power_leg(model, f1, f2, dev, seconds=4.0):
     import re
     import subprocess
 
+    # Under rocprofv3 the profiler's preloaded library initialises the GPU in every child process; rocm-smi is a
+    # `#!/usr/bin/env python3` script, so spawning it would exec from a GPU-initialised process - which this pool
+    # forbids (it takes the machine down).  Skip the leg there, and scrub the preload from the child's environment anyway.
+    preload = [k for k in os.environ if k.startswith(("ROCP", "ROCPROFILER", "ROCTRACER"))]
+    if "rocprof" in os.environ.get("LD_PRELOAD", "").lower() or preload:
+        return {"skipped": "a rocprofiler preload is active (LD_PRELOAD / " + ", ".join(sorted(preload)[:3]) + "): "
+                           "rocm-smi is not spawned under the profiler"}
+    child_env = {k: v for k, v in os.environ.items()
+                 if k != "LD_PRELOAD" and not k.startswith(("ROCP", "ROCPROFILER", "ROCTRACER", "HSA_TOOLS"))}
+
     def num(v):
         m = re.search(r"[-+]?\d+(\.\d+)?", str(v))
         return float(m.group(0)) if m else None
 
     def smi(*flags):
         out = subprocess.run(["rocm-smi", "-d", str(dev.index or 0), *flags, "--json"], capture_output=True,
-                             text=True, timeout=10).stdout
+                             text=True, timeout=10, env=child_env).stdout
         return next(iter(json.loads(out).values()))
 
     cap = None

@@ -21,7 +21,7 @@
 extern "C" {
 #endif
 
-#define FIUNET_ABI_VERSION 3
+#define FIUNET_ABI_VERSION 4   /* 4: fiunet_prepare_precision; fiunet_debug_read_activation takes the capacity of dst */
 
 enum fiunet_status {
     FIUNET_OK = 0,
@@ -31,7 +31,8 @@ enum fiunet_status {
     FIUNET_ERR_NOT_LOADED = 4,    /* forward before load_weights */
     FIUNET_ERR_WORKSPACE = 5,     /* workspace too small */
     FIUNET_ERR_HIP = 6,           /* a HIP runtime call failed; see fiunet_last_error_string */
-    FIUNET_ERR_UNSUPPORTED = 7    /* (reserved; bilinear=False returned this until round 4) */
+    FIUNET_ERR_UNSUPPORTED = 7    /* a value outside what the kernels cover (fiunet_ssim_gauss_f32: even or > 31 window;
+                                     read-back of an upsampled half that is never stored) */
 };
 
 /* Arithmetic type of the conv path.  FP32: fp32 storage, exact-fp32 MFMA (v_mfma_f32_16x16x4_f32).
@@ -40,10 +41,12 @@ enum fiunet_status {
 enum fiunet_precision {
     FIUNET_FP32 = 0,   /* exact fp32: v_mfma_f32_16x16x4_f32 (the reference's own arithmetic) */
     FIUNET_BF16 = 1,   /* bf16 storage and MFMA operands, fp32 accumulation */
-    FIUNET_BF16X2 = 2  /* round 4: the fp32 CONTRACT (|d| <= 1e-3) on the bf16 pipe - every activation and weight is two bf16
-                          pieces (hi + lo, 16 significant bits), a product is wh*xh + wl*xh + wh*xl with fp32 accumulation
-                          (~1e-5 relative end to end); fp32 frames in, fp32 logits out, exact-fp32 stem and head.
-                          bilinear=True only; the ablation / read-back options are not available in this mode */
+    FIUNET_BF16X2 = 2  /* the fp32 CONTRACT (|d| <= 1e-3) on the bf16 pipe - every activation and weight is two bf16
+                          pieces (hi + lo, 16 significant bits; activations [hi planes | lo planes], 4 B per element), a
+                          product is wh*xh + wl*xh + wh*xl with fp32 accumulation (~1e-5 relative end to end); fp32 frames
+                          in, fp32 logits out, exact-fp32 stem and head.  Needs fiunet_prepare_precision(ctx, FIUNET_BF16X2)
+                          once after fiunet_load_weights.  Both decoders; FIUNET_OPT_KEEP_ALL + read-back work, the other
+                          A/B options (UNFUSED, GATHER_UPSAMPLE, PAIR_TILES) are ignored in this mode */
 };
 
 /* Bit flags for fiunet_set_options. */
@@ -88,6 +91,13 @@ int fiunet_set_options(fiunet_ctx* ctx, unsigned flags);
  * layout for both precisions and owns the device copies. */
 int fiunet_load_weights(fiunet_ctx* ctx, int n, const char* const* names,
                         const float* const* host_ptrs, const int64_t* numels);
+
+/* Builds the weight copies a precision needs beyond what fiunet_load_weights made (FP32, BF16: nothing; BF16X2: the
+ * two-piece [wh | wl] copies, ~69 MB, packed on the device from the fp32 copy).  Call it after fiunet_load_weights and
+ * before the first forward in that precision (a forward without it returns FIUNET_ERR_NOT_LOADED); idempotent;
+ * allocates and synchronises - so not under stream capture.  The reference has no counterpart: its one precision is
+ * whatever dtype the module's tensors have (model/inference.py:96). */
+int fiunet_prepare_precision(fiunet_ctx* ctx, int precision);
 
 /* Bytes of device scratch fiunet_forward needs for a [B,*,H,W] batch; 0 on bad arguments.
  * Activations whose lifetimes do not overlap share bytes (the reference, under no_grad, frees every
@@ -180,12 +190,16 @@ int fiunet_ssim_gauss_f32(const float* img1, const float* img2, int images, int 
                           const float* window_1d, double* out_ssim, double* out_sqerr, void* workspace,
                           size_t workspace_bytes, void* stream);
 
-/* Parity-test hook: after a fiunet_forward on `workspace`, convert one intermediate activation
- * (NHWC in the compute precision) to fp32 NCHW at dst.  tap = 2*block + conv for the 18 fused
- * conv+BN+ReLU stages in state-dict order (0 = unet.inc.double_conv.0 ... 17 =
- * unet.up4.conv.double_conv.3).  out_dims receives {C, H, W} of that activation. */
+/* Parity-test hook: after a fiunet_forward on `workspace` (with FIUNET_OPT_KEEP_ALL set), convert one intermediate
+ * activation (blocked channels-last in the compute precision; two-piece in BF16X2) to fp32 NCHW at dst.  tap = 2*block
+ * + conv for the 18 fused conv+BN+ReLU stages in state-dict order (0 = unet.inc.double_conv.0 ... 17 =
+ * unet.up4.conv.double_conv.3); taps 18..21 = the upsampled + padded half of up1..up4's concat input (`self.up(x1)` +
+ * F.pad, unet.py:47-53) where it exists as a tensor (always with the ConvTranspose2d decoder and in BF16X2; for the
+ * bilinear decoder only where upsample_kernel materialises it - otherwise FIUNET_ERR_UNSUPPORTED).  out_dims receives
+ * {C, H, W} of that activation - C depends on the decoder (the ConvTranspose2d variant is wider at taps 8, 9, 11, 13, 15).  dst_capacity = floats dst can hold; B*C*H*W are written,
+ * FIUNET_ERR_INVALID_ARG if it is short.  dst == NULL: dims-only query (nothing is read, workspace may be NULL). */
 int fiunet_debug_read_activation(fiunet_ctx* ctx, const void* workspace, int B, int H, int W,
-                                 int precision, int tap, float* dst, int out_dims[3],
+                                 int precision, int tap, float* dst, size_t dst_capacity, int out_dims[3],
                                  void* stream);
 
 /* Measurement hook (bench.py's roofline leg): when enabled, every fiunet_forward records a HIP

@@ -111,8 +111,55 @@ def gen_convt():
         mine = O.unet_forward(sd, f1, f2)
         print(f"convt {name}: out std {out.std():.4f} min {out.min():.3f} max {out.max():.3f} "
               f"|restatement-ref| {float((mine - out).abs().max()):.3e}")
-        np.savez_compressed(os.path.join(GOLD, f"out_convt_{name}.npz"), seed=seed, weight_seed=WEIGHT_SEED,
-                            frame1=f1.numpy(), frame2=f2.numpy(), out=out.numpy())
+        if "--convt-layers-only" not in sys.argv:
+            np.savez_compressed(os.path.join(GOLD, f"out_convt_{name}.npz"), seed=seed, weight_seed=WEIGHT_SEED,
+                                frame1=f1.numpy(), frame2=f2.numpy(), out=out.numpy())
+    gen_convt_layers(model, sd)
+
+
+def gen_convt_layers(model, sd):
+    """Per-block activations of the default-constructed reference class (hooks on its modules, as for the bilinear
+    variant in main()): the 18 conv+BN+ReLU outputs, the four pools, the four `up{k}.up` ConvTranspose2d outputs
+    (unet.py:43,47 - before F.pad) and the head.  34x52 -> 17x26 -> 8x13 -> 4x6 -> 2x3: F.pad is live after up2
+    (one column) and up3 (one row) and absent after up1 / up4."""
+    f1, f2 = O.make_frames(25, 1, 34, 52)
+    acts = {}
+
+    def hook(name):
+        def fn(_m, _inp, outp):
+            acts[name] = outp.detach().clone()
+        return fn
+
+    handles = []
+    for mod_name, mod in model.named_modules():
+        if mod_name.endswith("double_conv.2") or mod_name.endswith("double_conv.5"):   # inplace ReLUs: see main()
+            conv_idx = "0" if mod_name.endswith(".2") else "3"
+            handles.append(mod.register_forward_hook(hook(mod_name.rsplit(".", 1)[0] + "." + conv_idx)))
+        if mod_name.endswith("maxpool_conv.0"):
+            handles.append(mod.register_forward_hook(hook(mod_name.split(".maxpool_conv")[0] + ".pool")))
+        if mod_name.startswith("unet.up") and mod_name.endswith(".up"):
+            assert isinstance(mod, torch.nn.ConvTranspose2d), mod
+            handles.append(mod.register_forward_hook(hook(mod_name)))
+        if mod_name == "unet.outc":
+            handles.append(mod.register_forward_hook(hook("unet.outc")))
+    with torch.no_grad():
+        model(f1, f2)
+    for hd in handles:
+        hd.remove()
+    assert len(acts) == 18 + 4 + 4 + 1, sorted(acts)
+    taps = {}
+    O.unet_forward(sd, f1, f2, taps)
+    fix = {}
+    for k, v in acts.items():
+        d = float((taps[k] - v).abs().max())
+        idx, vals = strided_sample(v, 1024)
+        fix[f"{k}|idx"] = idx
+        fix[f"{k}|val"] = vals
+        fix[f"{k}|sum"] = np.float64(v.double().sum().item())
+        fix[f"{k}|abssum"] = np.float64(v.double().abs().sum().item())
+        fix[f"{k}|shape"] = np.array(v.shape, dtype=np.int64)
+        print(f"  convt layer {k:42s} shape {tuple(v.shape)} |restatement-ref| {d:.2e}")
+    np.savez_compressed(os.path.join(GOLD, "layers_convt_b1_34x52.npz"), frame1=f1.numpy(), frame2=f2.numpy(), **fix)
 
 
 def make_ssim_pair(seed, b, c, h, w, rng_kind, noise):
@@ -170,7 +217,7 @@ def main():
     if "--ssim-only" in sys.argv:
         os.makedirs(GOLD, exist_ok=True)
         return gen_ssim()
-    if "--convt-only" in sys.argv:  # add the bilinear=False fixtures without re-recording the others
+    if "--convt-only" in sys.argv or "--convt-layers-only" in sys.argv:  # add the bilinear=False fixtures without re-recording the others
         os.makedirs(GOLD, exist_ok=True)
         return gen_convt()
     if "--rgb-only" in sys.argv:  # add the RGB fixtures without re-recording the others

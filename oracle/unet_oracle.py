@@ -203,13 +203,16 @@ def _double_conv(x, sd, prefix, taps):
     return x
 
 
-def upsample_pad_concat(x_low, x_skip, up_weight=None, up_bias=None):
+def upsample_pad_concat(x_low, x_skip, up_weight=None, up_bias=None, taps=None, tap_name=None):
     """unet.py:46-54 -- bilinear x2 (align_corners=True), or ConvTranspose2d(k=2, s=2) when the checkpoint has
-    one (bilinear=False, unet.py:42-44); asymmetric zero pad, cat([skip, up])."""
+    one (bilinear=False, unet.py:42-44); asymmetric zero pad, cat([skip, up]).  taps[tap_name] = `self.up(x1)`
+    (unet.py:47), i.e. BEFORE F.pad."""
     if up_weight is not None:
         up = F.conv_transpose2d(x_low, up_weight, up_bias, stride=2)
     else:
         up = F.interpolate(x_low, scale_factor=2, mode="bilinear", align_corners=True)
+    if taps is not None and tap_name:
+        taps[tap_name] = up
     dy = x_skip.shape[2] - up.shape[2]
     dx = x_skip.shape[3] - up.shape[3]
     up = F.pad(up, [dx // 2, dx - dx // 2, dy // 2, dy - dy // 2])
@@ -230,7 +233,8 @@ def unet_forward(sd, frame1, frame2, taps=None):
         cur = _double_conv(cur, sd, f"unet.down{k}.maxpool_conv.1", taps)
         skips.append(cur)
     for k, skip in zip((1, 2, 3, 4), (skips[3], skips[2], skips[1], skips[0])):
-        cat = upsample_pad_concat(cur, skip, sd.get(f"unet.up{k}.up.weight"), sd.get(f"unet.up{k}.up.bias"))
+        cat = upsample_pad_concat(cur, skip, sd.get(f"unet.up{k}.up.weight"), sd.get(f"unet.up{k}.up.bias"), taps,
+                                  f"unet.up{k}.up")
         if taps is not None:
             taps[f"unet.up{k}.cat"] = cat
         cur = _double_conv(cat, sd, f"unet.up{k}.conv", taps)

@@ -1,6 +1,6 @@
 /* Plain-C consumer of the C ABI (include/fiunet.h): no Python, no torch, only the HIP runtime for
- * device memory.  Loads a weight blob + two frames from files, runs fiunet_forward in both
- * precisions and writes the outputs.  tests/test_gpu_cabi.py builds and runs it, then compares the
+ * device memory.  Loads a weight blob + two frames from files, runs fiunet_forward in the three
+ * precisions and writes the outputs; also walks the error paths a C caller can hit.  tests/test_gpu_cabi.py builds and runs it, then compares the
  * outputs with the oracle.
  *
  * blob format (little endian): int32 n_tensors; per tensor: int32 name_len, name bytes, int64 numel,
@@ -64,7 +64,28 @@ int main(int argc, char** argv)
     if (fiunet_forward(ctx, d1, d2, dout, B, H, W, FIUNET_FP32, d1, 16, NULL) != FIUNET_ERR_WORKSPACE) return 6;
     hipStream_t stream;
     HK(hipStreamCreate(&stream));
-    for (int prec = 0; prec < 2; ++prec) {
+    /* bf16x2 needs its two-piece weight copies first */
+    {
+        const size_t wsb = fiunet_workspace_bytes(ctx, B, H, W, FIUNET_BF16X2);
+        void* ws = NULL;
+        if (!wsb) return 7;
+        HK(hipMalloc(&ws, wsb));
+        if (fiunet_forward(ctx, d1, d2, dout, B, H, W, FIUNET_BF16X2, ws, wsb, NULL) != FIUNET_ERR_NOT_LOADED) return 8;
+        HK(hipFree(ws));
+        CK(fiunet_prepare_precision(ctx, FIUNET_BF16X2));
+        CK(fiunet_prepare_precision(ctx, FIUNET_BF16X2));   /* idempotent */
+    }
+    /* read-back: dims-only query, then a buffer that is too short */
+    {
+        int dims3[3] = {0, 0, 0};
+        CK(fiunet_debug_read_activation(ctx, NULL, B, H, W, FIUNET_FP32, 9, NULL, 0, dims3, NULL));
+        if (dims3[0] != 512 || dims3[1] != H / 16 || dims3[2] != W / 16) return 9;
+        CK(fiunet_set_options(ctx, FIUNET_OPT_KEEP_ALL));
+        if (fiunet_debug_read_activation(ctx, d1, B, H, W, FIUNET_FP32, 9, dout, 16, dims3, NULL) != FIUNET_ERR_INVALID_ARG) return 10;
+        CK(fiunet_set_options(ctx, 0));
+    }
+    static const char* const kPrecName[3] = {"fp32", "bf16", "bf16x2"};
+    for (int prec = 0; prec < 3; ++prec) {
         const size_t wsb = fiunet_workspace_bytes(ctx, B, H, W, prec);
         if (!wsb) return 7;
         void* ws = NULL;
@@ -73,7 +94,7 @@ int main(int argc, char** argv)
         HK(hipStreamSynchronize(stream));
         HK(hipMemcpy(ho, dout, 4 * npx, hipMemcpyDeviceToHost));
         char path[512];
-        snprintf(path, sizeof path, "%s_%s.bin", argv[3], prec ? "bf16" : "fp32");
+        snprintf(path, sizeof path, "%s_%s.bin", argv[3], kPrecName[prec]);
         FILE* o = fopen(path, "wb");
         if (!o) return 1;
         fwrite(ho, 4, npx, o);

@@ -45,3 +45,5 @@ def test_plain_c_consumer(tmp_path, seeded_sd, hip_lib_built):
     o16 = np.fromfile(tmp_path / "out_bf16.bin", dtype=np.float32).reshape(ref.shape)
     assert np.abs(o32 - ref).max() <= 1e-3
     assert np.linalg.norm(o16 - ref) / np.linalg.norm(ref) <= 2e-2
+    ox2 = np.fromfile(tmp_path / "out_bf16x2.bin", dtype=np.float32).reshape(ref.shape)
+    assert np.abs(ox2 - ref).max() <= 1e-3

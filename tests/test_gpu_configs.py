@@ -471,10 +471,71 @@ def test_bf16x2_larger_frames_bands_u8_rgb_and_psnr(dev, seeded_sd):
     ref_u8 = O.postprocess_tensor(O.unet_forward(sdi, O.preprocess_array(x.numpy()), O.preprocess_array(z.numpy())))
     hip_u8 = mi.forward_u8(x[None, None].to(dev), z[None, None].to(dev))[0, 0].cpu().numpy()
     assert abs(O.psnr_u8(truth.numpy(), hip_u8) - O.psnr_u8(truth.numpy(), ref_u8)) <= 0.002
-    # not available in this mode: the ConvTranspose2d decoder, the per-layer read-back
-    mc = P.FrameInterpolationUNet(precision="bf16x2")
-    mc.load_state_dict(O.make_seeded_state_dict(1234, bilinear=False))
-    with pytest.raises(RuntimeError):
-        mc.to(dev).eval()(f1[:1, :, :32, :32].contiguous().to(dev), f2[:1, :, :32, :32].contiguous().to(dev))
-    with pytest.raises(RuntimeError):
-        m.debug_activations(f1[:1].to(dev), f2[:1].to(dev))
+    # the per-layer read-back at a size with un-split kernels and several tiles (taps + the four materialised
+    # upsampled halves, which the oracle records before F.pad)
+    taps = {}
+    O.unet_forward(seeded_sd, f1[:1], f2[:1], taps)
+    acts, _ = m.debug_activations(f1[:1].to(dev), f2[:1].to(dev), with_up=True)
+    assert len(acts) == 22
+    for name, a in acts.items():
+        r = taps[name]
+        if name.endswith(".up"):
+            dy, dx = a.shape[2] - r.shape[2], a.shape[3] - r.shape[3]
+            r = torch.nn.functional.pad(r, [dx // 2, dx - dx // 2, dy // 2, dy - dy // 2])
+        assert a.shape == r.shape, name
+        assert (a.cpu() - r).abs().max().item() <= 2e-4 * r.abs().max().item(), name
+
+
+@pytest.mark.parametrize("name", _CONVT_GOLD)
+def test_bf16x2_convtranspose_variant_meets_the_fp32_contract(convt_model, dev, golden_dir, name):
+    """bilinear=False (the reference's default constructor, unet.py:42-44,66,99) in precision bf16x2: the transposed
+    convs run on two-piece operands too (convt2x2_kernel<bf16, X2>); against the real class's outputs."""
+    g = np.load(os.path.join(golden_dir, f"out_convt_{name}.npz"))
+    f1, f2, ref = torch.from_numpy(g["frame1"]), torch.from_numpy(g["frame2"]), torch.from_numpy(g["out"])
+    convt_model.precision = "bf16x2"
+    convt_model.set_options()
+    try:
+        out = convt_model(f1.to(dev), f2.to(dev)).cpu()
+    finally:
+        convt_model.precision = "fp32"
+    d = (out - ref).abs().max().item()
+    assert out.shape == ref.shape and d <= FP32_TOL and d <= 2e-4 * max(1.0, ref.abs().max().item()), d
+
+
+@pytest.mark.parametrize("prec", ["fp32", "bf16", "bf16x2"])
+def test_convtranspose_variant_per_layer_golden_fixture(convt_model, dev, golden_dir, prec):
+    """`FrameInterpolationUNet()` (bilinear=False) stage by stage against activations recorded from the reference's
+    own default-constructed class (oracle/gen_golden.py gen_convt_layers: hooks on its ReLUs and on its four
+    ConvTranspose2d modules): 18 conv+BN+ReLU outputs + the four `up{k}.up` outputs (ours are stored already
+    padded: the fixture's window is cut out of them, and the padding must be exactly zero) + the head.
+    34x52: F.pad is live after up2 (a column) and up3 (a row).  This is also the regression test of the read-back's
+    buffer sizing for this wider decoder (taps 8, 9, 11, 13, 15 have twice the bilinear variant's channels)."""
+    g = np.load(os.path.join(golden_dir, "layers_convt_b1_34x52.npz"))
+    convt_model.precision = prec
+    convt_model.set_options()
+    try:
+        acts, out = convt_model.debug_activations(torch.from_numpy(g["frame1"]).to(dev),
+                                                  torch.from_numpy(g["frame2"]).to(dev), with_up=True)
+    finally:
+        convt_model.precision = "fp32"
+    assert len(acts) == 22
+    rel_tol = {"fp32": 1e-5, "bf16x2": 2e-4, "bf16": 2.5e-2}[prec]
+    for name, a in acts.items():
+        shape = tuple(g[f"{name}|shape"])
+        a = a.cpu()
+        if name.endswith(".up"):   # ours: after F.pad (unet.py:49-53: left/top get diff // 2)
+            dy, dx = a.shape[2] - shape[2], a.shape[3] - shape[3]
+            assert 0 <= dy <= 1 and 0 <= dx <= 1, (name, a.shape, shape)
+            inner = a[:, :, dy // 2:dy // 2 + shape[2], dx // 2:dx // 2 + shape[3]]
+            outside = torch.ones_like(a, dtype=torch.bool)
+            outside[:, :, dy // 2:dy // 2 + shape[2], dx // 2:dx // 2 + shape[3]] = False
+            assert not a[outside].any(), name   # the padding is exactly zero
+            a = inner.contiguous()
+        assert tuple(a.shape) == shape, (name, a.shape, shape)
+        got = a.reshape(-1)[torch.from_numpy(g[f"{name}|idx"])].numpy()
+        want = g[f"{name}|val"]
+        assert np.abs(got - want).max() <= rel_tol * max(1.0, np.abs(want).max()), (name, np.abs(got - want).max())
+    got = out.cpu().reshape(-1)[torch.from_numpy(g["unet.outc|idx"])].numpy()
+    want = g["unet.outc|val"]
+    tol = FP32_TOL if prec != "bf16" else 0.04 * (want.max() - want.min())
+    assert np.abs(got - want).max() <= tol

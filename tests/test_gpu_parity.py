@@ -72,8 +72,11 @@ def test_bf16_matches_reference_golden(model, dev, golden_dir, name):
     assert O.psnr_u8(u_ref, u_hip) >= 35.0
 
 
-@pytest.mark.parametrize("prec,unfused", [("fp32", False), ("fp32", True), ("bf16", False), ("bf16", True)])
+@pytest.mark.parametrize("prec,unfused", [("fp32", False), ("fp32", True), ("bf16", False), ("bf16", True),
+                                          ("bf16x2", False)])
 def test_per_layer_against_oracle(model, dev, seeded_sd, prec, unfused):
+    """All 18 conv+BN+ReLU outputs against the oracle's.  bf16x2 (two-piece activations, 16 significant bits; its
+    read-back adds the pieces): every layer within 2e-4 of its own range, whole net within the fp32 contract."""
     f1, f2 = O.make_frames(11, 1, 32, 48)
     taps = {}
     ref = O.unet_forward(seeded_sd, f1, f2, taps)
@@ -88,8 +91,9 @@ def test_per_layer_against_oracle(model, dev, seeded_sd, prec, unfused):
         r = taps[name]
         assert a.shape == r.shape
         rel = (a.cpu() - r).abs().max().item() / r.abs().max().item()
-        assert rel <= (1e-5 if prec == "fp32" else 2e-2), (name, rel)
-    tol = FP32_TOL if prec == "fp32" else 0.04 * (ref.max() - ref.min()).item()
+        assert rel <= {"fp32": 1e-5, "bf16x2": 2e-4, "bf16": 2e-2}[prec], (name, rel)
+    tol = FP32_TOL if prec in ("fp32", "bf16x2") else 0.04 * (ref.max() - ref.min()).item()
+    model.precision = "fp32"
     assert (out.cpu() - ref).abs().max().item() <= tol
 
 

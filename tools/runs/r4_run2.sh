@@ -9,7 +9,7 @@ R=$PWD
 cd /tmp && export TMPDIR=/tmp
 for v in base xcd8; do
   if [ $v = xcd8 ]; then export FIUNET_XCD_CT=8; else unset FIUNET_XCD_CT; fi
-  timeout -k 10 200 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $R/$O/pmc_$v -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --video-frames 0 --no-fp32 > $R/$O/pmc_$v.log 2>&1
+  timeout -k 10 200 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $R/$O/pmc_$v -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --video-frames 0 --no-fp32 --no-power > $R/$O/pmc_$v.log 2>&1
   python3 $R/tools/pmc_fetch_by_dispatch.py $R/$O/pmc_$v 3 > $R/$O/pmc_fetch_$v.txt 2>&1
   find $R/$O/pmc_$v -name "*.csv" -delete
 done
