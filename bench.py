@@ -4,6 +4,9 @@
     python bench.py [--gpus N] [--steps K] [--warmup W]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
+Both forms work for N > 1: started WITHOUT a launcher (no WORLD_SIZE in the environment), `--gpus N` makes this
+process a launcher itself - it starts N child ranks (one per GPU, RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set,
+rendezvous on 127.0.0.1), relays rank 0's JSON line and exits with the worst child status (`launch_ranks`).
 
 A step = one forward of the hot path over one batch of synthetic frame pairs that is already
 resident in HBM.  Default workload = BASELINE.json configs[2]: batch 8 of 1920x1080 pairs, bf16
@@ -396,6 +399,51 @@ def tile4k_leg(model, dev, dist, rank, world, reps):
     return res
 
 
+def launch_ranks(n: int) -> int:
+    """`python bench.py --gpus N` with no launcher around it: be the launcher.  This process has made NO GPU call
+    (importing torch and this package does not initialise HIP; nothing below does either) and never exec()s: it
+    starts N CHILD processes, one rank per GPU, with the environment torch.distributed.run would give them, relays
+    rank 0's stdout (the one JSON line) and returns the worst child status.  A child that fails or dies takes the
+    others down after a grace period (they would wait in a collective for ever), by their exact PIDs."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:   # a free rendezvous port on the loopback interface
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+        # rank 0's stdout is the result line; the other ranks' stdout (RCCL banners) goes to stderr
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__), *sys.argv[1:]], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else sys.stderr, text=(r == 0)))
+    out0 = []
+    reader = threading.Thread(target=lambda: out0.extend(procs[0].stdout.readlines()), daemon=True)
+    reader.start()
+    worst, deadline = 0, None
+    while any(p.poll() is None for p in procs):
+        time.sleep(0.2)
+        bad = [p.returncode for p in procs if p.poll() not in (None, 0)]
+        if bad and deadline is None:
+            deadline = time.time() + 30.0        # let the others report, then stop them
+        if deadline is not None and time.time() > deadline:
+            for p in procs:
+                if p.poll() is None:
+                    p.kill()
+    reader.join(10.0)
+    for p in procs:
+        rc = p.returncode if p.returncode is not None else 1
+        worst = max(worst, rc if rc > 0 else (128 - rc if rc < 0 else 0))
+    lines = [l for l in out0 if l.strip()]
+    for l in lines:
+        sys.stdout.write(l)
+    sys.stdout.flush()
+    if worst == 0 and not any(l.lstrip().startswith("{") for l in lines):
+        print("bench.py launcher: rank 0 exited 0 without a result line", file=sys.stderr)
+        worst = 1
+    return worst
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -414,17 +462,33 @@ def main():
     ap.add_argument("--no-power", action="store_true", help="skip the rocm-smi power / clock sample")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(launch_ranks(args.gpus))   # no launcher around us: be one (no GPU call so far, none in there)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus != world:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N > 1")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: start one rank per GPU "
+                         "(`python bench.py --gpus N` does it by itself)")
     dist = None
-    # Rehearsal only (never set by the driver): FIUNET_BENCH_REHEARSE=1 runs the N-rank flow on ONE card -
+    # Rehearsals only (never set by the driver).  FIUNET_BENCH_REHEARSE=1 runs the N-rank flow on ONE card -
     # every rank on cuda:0, gloo instead of RCCL (which needs one GPU per rank) - to exercise the multi-rank
-    # code paths of this file on a one-GPU box; its numbers mean nothing.
+    # code paths of this file on a one-GPU box; its numbers mean nothing.  FIUNET_BENCH_REHEARSE=launcher (the
+    # CPU test of `launch_ranks`, tests/test_dist.py) stops after the rendezvous: no GPU, no forward, no number.
     rehearse = os.environ.get("FIUNET_BENCH_REHEARSE") == "1"
+    if os.environ.get("FIUNET_BENCH_REHEARSE") == "launcher":
+        import torch.distributed as dist
+        with _quiet_native_stdout():                 # gloo prints its connection banner on fd 1
+            dist.init_process_group("gloo", timeout=datetime.timedelta(seconds=120))
+            t = torch.tensor([float(rank)], dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)     # the reduction the timed region's maximum takes
+            dist.barrier()
+        if rank == 0:
+            print(json.dumps({"rehearsal": "launcher only: rendezvous + max-reduce over gloo, no forward was run",
+                              "value": None, "n_gpus": world, "ranks_seen": dist.get_world_size(),
+                              "max_rank_reduced": int(t.item()), "steps": args.steps, "warmup": args.warmup}))
+        dist.destroy_process_group()
+        return
     if rehearse:
         local_rank = 0
     if world > 1 or "RANK" in os.environ:  # under torch.distributed.run (also with one rank)
@@ -829,6 +893,10 @@ def headline(args, world, elapsed, rows, nfw, default_workload, video_res, tile_
             roofline["whole_forward"]["mfma_frac_at_sustained_clock"] = round(roofline["whole_forward"]["tflops"] / pk, 4)
     if video_res is not None:
         result["video_sharded"] = video_res
+        if world > 1:   # what the communicator actually did, where a reader of the N > 1 line looks first
+            result["rccl_ranks_seen"] = video_res.get("ranks")
+            result["pairs_per_rank"] = video_res.get("pairs_per_rank")
+            result["collective_backend"] = video_res.get("backend")
     if tile_res is not None:
         result["tile4k"] = tile_res
     return result

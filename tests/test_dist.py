@@ -201,3 +201,44 @@ def test_broadcast_model_weights_world2():
         assert p.exitcode == 0
     res = sorted(q.get(timeout=5) for _ in range(2))
     assert res == [(0, True, False), (1, True, True)]
+
+
+def test_bench_gpus_n_launches_its_own_ranks(tmp_path):
+    """`python bench.py --gpus 2` with no launcher around it (how the driver invokes bench.py) must start the two
+    ranks itself, relay exactly one JSON line from rank 0 and exit 0.  CPU rehearsal of the launcher only
+    (FIUNET_BENCH_REHEARSE=launcher: gloo rendezvous + the max-reduction, no forward, no number); the same entry with
+    the real forward behind it runs on the GPU box (tests/test_gpu_dist.py)."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    env["FIUNET_BENCH_REHEARSE"] = "launcher"
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1"],
+                       env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, r.stdout
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["ranks_seen"] == 2 and d["max_rank_reduced"] == 1 and d["steps"] == 3
+    # ranks that fail must show in the launcher's exit status and leave stdout empty: without the rehearsal switch
+    # the ranks go for their GPUs, and this box has none (there is no CPU fallback to fall into)
+    if not torch.cuda.is_available():
+        del env["FIUNET_BENCH_REHEARSE"]
+        r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1"],
+                           env=env, capture_output=True, text=True, timeout=300)
+        assert r.returncode != 0 and not r.stdout.strip(), (r.returncode, r.stdout)
+
+
+def test_bench_launcher_parent_makes_no_gpu_call():
+    """The launching process must not initialise HIP (on this pool a GPU-initialised process may not start the ranks
+    the way a launcher does): nothing in `launch_ranks` or on the way to it touches torch.cuda or the native library."""
+    import ast
+    import inspect
+    import bench
+    src = inspect.getsource(bench.launch_ranks)
+    assert "torch.cuda" not in src and "_native" not in src and "os.exec" not in src and "execv" not in src
+    main_src = inspect.getsource(bench.main)
+    upto = main_src.index("launch_ranks(args.gpus)")
+    assert "torch.cuda" not in main_src[:upto] and "model" not in main_src[:upto]
+    ast.parse(src)

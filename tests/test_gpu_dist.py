@@ -136,3 +136,27 @@ def test_sharded_video_two_ranks_on_one_gpu(prec, h, w):
 def test_tiled_forward_two_ranks_on_one_gpu():
     kind, p, equal, _, where = _run(_tile_worker, "bf16", 2160, 3840)
     assert (kind, p) == ("tile", "bf16") and equal, where
+
+
+def test_bench_gpus_2_self_launches_on_one_card():
+    """`python bench.py --gpus 2` exactly as the driver would type it (no torch.distributed.run around it): the
+    process launches its two ranks itself.  One-card REHEARSAL (FIUNET_BENCH_REHEARSE=1: both ranks on cuda:0, gloo
+    instead of RCCL, numbers meaningless) with the real forward and the sharded video leg behind it: one JSON line,
+    rc 0, both ranks seen, the pairs split 4 + 4, the spot check against the single-GPU result green."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    env["FIUNET_BENCH_REHEARSE"] = "1"
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+                        "--batch", "2", "--height", "360", "--width", "640", "--no-cpu-baseline", "--no-power",
+                        "--no-fp32", "--video-frames", "9"], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["value"] > 0 and d["scaling"] == "weak"
+    assert d["rccl_ranks_seen"] == 2 and d["pairs_per_rank"] == [4, 4], d
+    assert d["video_sharded"]["spot_check_equal_to_single_gpu"] is True
+    assert "REHEARSAL" in d["collective_backend"]
