@@ -29,6 +29,7 @@ OPT_RNE_WEIGHTS, OPT_NO_DITHER = 32, 64
 SYMBOLS = (
     "fiunet_abi_version", "fiunet_last_error_string", "fiunet_create", "fiunet_destroy",
     "fiunet_set_options", "fiunet_load_weights", "fiunet_prepare_precision", "fiunet_workspace_bytes", "fiunet_forward",
+    "fiunet_min_unsplit_batch",
     "fiunet_forward_strip",
     "fiunet_workspace_bytes_u8", "fiunet_forward_u8", "fiunet_preprocess_u8",
     "fiunet_postprocess_u8", "fiunet_debug_read_activation", "fiunet_profile_enable",
@@ -85,6 +86,8 @@ def lib() -> ctypes.CDLL:
     L.fiunet_prepare_precision.argtypes = [vp, ci]
     L.fiunet_workspace_bytes.argtypes = [vp, ci, ci, ci, ci]
     L.fiunet_workspace_bytes.restype = sz
+    L.fiunet_min_unsplit_batch.argtypes = [vp, ci, ci, ci]
+    L.fiunet_min_unsplit_batch.restype = ci
     L.fiunet_workspace_bytes_u8.argtypes = [vp, ci, ci, ci, ci]
     L.fiunet_workspace_bytes_u8.restype = sz
     L.fiunet_forward.argtypes = [vp, vp, vp, vp, ci, ci, ci, ci, vp, sz, vp]
@@ -176,6 +179,13 @@ class Context:
                 raise RuntimeError(f"input {h}x{w} has 2^26 pixels or more: cut it into row bands "
                                    "(tiling.forward_tiled / forward_strip)")
             check(1, "fiunet_workspace_bytes")
+        return n
+
+    def min_unsplit_batch(self, h, w, precision) -> int:
+        """Smallest batch at which no layer of an h x w forward K-splits (65: none up to 64)."""
+        n = lib().fiunet_min_unsplit_batch(self._h, h, w, precision)
+        if n == 0:
+            check(1, "fiunet_min_unsplit_batch")
         return n
 
     def forward(self, f1, f2, out, precision, workspace, stream=None):

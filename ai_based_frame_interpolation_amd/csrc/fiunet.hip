@@ -337,6 +337,21 @@ int launch_pair_cfg(ConvArgs a, hipStream_t s)
     return FIUNET_OK;
 }
 
+// K-split rule of one conv (launch_conv_maybe_split and fiunet_min_unsplit_batch share it): `nblk` workgroups
+// without a split, `nplanes` K-loop planes, B images of H x W with Cout output channels.  Returns the number of K
+// slices (1 = no split).  Fewer workgroups than CUs: cut K as well.  The cut changes the fp32 summation order, so it
+// must not depend on the batch size for frames whose batches are compared bit for bit (a video's ragged last chunk,
+// B=1 vs B=8 at 1080p): layers with >= 64 workgroups PER IMAGE keep round 1's rule (split below 128 workgroups in
+// total, which such a layer never has for B >= 2 - a SINGLE pair with 64..127 workgroups per image, e.g. the deepest
+// level of a 720p frame, does split); small frames, where a single pair is K-split anyway, split below 256.
+inline int ksplit_rule(long long nblk, int nplanes, int B, int H, int W, int Cout)
+{
+    int ksplit = (int)std::min<long long>(std::min(nplanes / 2, 16), (256 + nblk - 1) / nblk);
+    while (ksplit > 1 && (size_t)ksplit * B * H * W * Cout * 4 > kSlabBytes) --ksplit;
+    const long long thr = nblk / B < 64 ? 256 : 128;
+    return (nblk < thr && ksplit > 1) ? ksplit : 1;
+}
+
 // pair kernel: direct sources, plain / pooled epilogue, enough tile pairs to fill the 256 CUs
 template <typename T, int BN, int TH, int TW, int MODE, int EPI>
 constexpr bool pair_capable() { return MODE == SRC_DIRECT && (EPI == EPI_PLAIN || EPI == EPI_POOL) && BN == 128; }
@@ -352,16 +367,8 @@ int launch_conv_maybe_split(ConvArgs a, hipStream_t s)
     if constexpr (MODE != SRC_STEM && (EPI == EPI_PLAIN || EPI == EPI_POOL)) {
         const long long nblk = (long long)a.B * ((a.W + TW - 1) / TW) * ((a.H + TH - 1) / TH) * (a.Cout / BN);
         const int nplanes = (a.C0 + a.C1) / Elem<T>::PL * (X2 ? 3 : 1);
-        int ksplit = (int)std::min<long long>(std::min(nplanes / 2, 16), (256 + nblk - 1) / nblk);
-        while (ksplit > 1 && (size_t)ksplit * a.B * a.H * a.W * a.Cout * 4 > kSlabBytes) --ksplit;
-        // Fewer workgroups than CUs: cut K as well.  The cut changes the fp32 summation order, so it
-        // must not depend on the batch size for frames whose batches are compared bit for bit (a
-        // video's ragged last chunk, B=1 vs B=8 at 1080p): layers with >= 64 workgroups PER IMAGE
-        // keep round 1's rule (split below 128 workgroups in total, which such a layer never has
-        // for B >= 2 - a SINGLE pair with 64..127 workgroups per image, e.g. the deepest level of a 720p
-        // frame, does split); small frames, where a single pair is K-split anyway, split below 256.
-        const long long thr = nblk / a.B < 64 ? 256 : 128;
-        if (nblk < thr && ksplit > 1 && a.kslab && a.dst) {
+        const int ksplit = ksplit_rule(nblk, nplanes, a.B, a.H, a.W, a.Cout);
+        if (ksplit > 1 && a.kslab && a.dst) {
             ConvArgs k = a;
             k.ksplit = ksplit;
             int rc = launch_conv_cfg<T, BN, TH, TW, MODE, EPI_SPLITK>(k, s);
@@ -1019,6 +1026,34 @@ int fiunet_prepare_precision(fiunet_ctx* ctx, int precision)
     HIP_TRY(hipDeviceSynchronize());
     ctx->x2_ready = true;
     return FIUNET_OK;
+}
+
+int fiunet_min_unsplit_batch(const fiunet_ctx* ctx, int H, int W, int precision)
+{
+    if (!ctx || H < 16 || W < 16 || (precision != FIUNET_FP32 && precision != FIUNET_BF16 && precision != FIUNET_BF16X2)) {
+        g_err = "fiunet_min_unsplit_batch: bad arguments";
+        return 0;
+    }
+    const int PL = precision == FIUNET_FP32 ? 16 : 32;
+    int hs[5] = {H}, ws[5] = {W};
+    for (int k = 1; k < 5; ++k) { hs[k] = hs[k - 1] / 2; ws[k] = ws[k - 1] / 2; }
+    const bool fused_stem = plan_opts(ctx, H, W, precision).fused_stem;
+    for (int B = 1; B <= 64; ++B) {
+        bool split = false;
+        for (int i = 1; i < NCONV - 1 && !split; ++i) {   // conv 0 = stem kernel, conv 17 is never cut (fused head)
+            if (i == 1 && fused_stem) continue;            // SRC_STEM launches are never cut
+            const int h = hs[kLevel[i]], w = ws[kLevel[i]], cout = ctx->cout[i];
+            // the tile the launch would pick (launch_conv_shape)
+            int BN, TH, TW;
+            if (cout == 64) { BN = 64; const bool wide = prefer_wide(h, w, 16, 32, 32, 16); TH = wide ? 16 : 32; TW = wide ? 32 : 16; }
+            else { BN = 128; const bool wide = prefer_wide(h, w, 8, 32, 16, 16); TH = wide ? 8 : 16; TW = wide ? 32 : 16; }
+            const long long nblk = (long long)B * ((w + TW - 1) / TW) * ((h + TH - 1) / TH) * (cout / BN);
+            const int nplanes = ctx->conv[i].cin / PL * (precision == FIUNET_BF16X2 ? 3 : 1);
+            split = ksplit_rule(nblk, nplanes, B, h, w, cout) > 1;
+        }
+        if (!split) return B;
+    }
+    return 65;
 }
 
 size_t fiunet_workspace_bytes(const fiunet_ctx* ctx, int B, int H, int W, int precision)

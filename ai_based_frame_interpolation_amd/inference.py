@@ -135,16 +135,20 @@ def _forward_u8_chunk(model, a: torch.Tensor, b: torch.Tensor, batch: int) -> to
     than the chip has CUs and cut their K loop over several (split-K, fiunet.hip); how many depends on the
     batch (at 720p a single pair still splits its deepest level, two or more do not), so the fp32 summation
     order - hence a pixel sitting on a uint8 truncation boundary - of a pair may depend on how many pairs
-    share its call.  EVERY ragged chunk of such frames - the last one of a sequence, and the only one of a
-    sequence shorter than a batch - is therefore run as a full batch (its last pair repeated, the extra
-    outputs dropped): every pair of a sequence is computed exactly as in a full batch, and the result does
-    not depend on the sequence length or on how the sequence is sharded over ranks (`sequence_pair_fn`).
-    The area test is a proxy for the per-layer workgroup rule of `launch_conv_maybe_split`: from 1080p up
-    no layer ever splits, whatever the batch."""
+    share its call.  A ragged chunk - the last one of a sequence, and the only one of a sequence shorter than
+    a batch - is therefore padded (its last pair repeated, the extra outputs dropped) up to the smallest batch
+    at which no layer splits (`model.batch_invariant_from`, the library's own rule: 1 from 1080p up, 2 at 720p),
+    or to the full `batch` where even that still splits (256x256 at batch 8): every pair of a sequence is
+    computed exactly as in a full batch, the result does not depend on the sequence length or on how the
+    sequence is sharded over ranks (`sequence_pair_fn`) - and a one-pair 720p clip costs 2 forwards, not 8."""
     cnt = a.shape[0]
-    if cnt < batch and a.shape[-2] * a.shape[-1] < 1920 * 1080:
+    target = cnt
+    if cnt < batch:
+        bmin = model.batch_invariant_from(a.shape[-2], a.shape[-1], a.device)
+        target = batch if bmin > batch else max(cnt, bmin)
+    if target > cnt:
         rep = [1] * a.dim()
-        rep[0] = batch - cnt
+        rep[0] = target - cnt
         a = torch.cat([a, a[-1:].repeat(*rep)])
         b = torch.cat([b, b[-1:].repeat(*rep)])
         return model.forward_u8(a, b)[:cnt]

@@ -10,8 +10,10 @@ Based on Polynomial Expansion" (SCIA 2003), in the form OpenCV's `optflowgf.cpp`
 pyramid, per-level polynomial expansion (separable Gaussian-weighted least squares), iterative displacement
 update over a box-filtered normal-equation field, border attenuation - and remap's 5-bit fixed-point bilinear
 sampling.  **Parity unpinned**: nothing here has been compared with OpenCV's output; what the tests pin is the
-behaviour the algorithm must have (a translated texture yields that translation; the baseline beats the linear
-blend on moving content; remap with zero flow is the identity).  When `cv2` IS importable the evaluator calls
+behaviour the algorithm must have (a translated texture yields that translation; remap with zero flow is the
+identity) and the reference's own quirk, which is kept: it samples frame 0 at grid + flow / 2, i.e. AGAINST the
+motion, so on translating content this baseline scores BELOW the linear blend (evaluation.py's docstring and
+tests/test_host.py::test_optical_flow_baseline_is_the_references_formula).  When `cv2` IS importable the evaluator calls
 OpenCV itself (evaluation.py) and this module is not used.
 
 Everything is plain torch on whatever device the frames are on (host plumbing, not a hot path: the reference

@@ -303,6 +303,12 @@ class FrameInterpolationUNet(nn.Module):
             ctx.forward(f1, f2, out, prec, ws)
         return out if in_dtype == torch.float32 else out.to(in_dtype)
 
+    def batch_invariant_from(self, height: int, width: int, device=None) -> int:
+        """Smallest batch at which the result of a pair no longer depends on the batch it is part of (no layer cuts
+        its K loop over workgroups: include/fiunet.h, fiunet_min_unsplit_batch).  1 from 1080p up, 2 at 720p."""
+        dev = device if device is not None else next(self.parameters()).device
+        return self._context(torch.device(dev)).min_unsplit_batch(int(height), int(width), self._precision_code())
+
     @torch.no_grad()
     def forward_strip(self, frame1: torch.Tensor, frame2: torch.Tensor, y_origin: int,
                       image_height: int) -> torch.Tensor:

@@ -106,6 +106,13 @@ int fiunet_prepare_precision(fiunet_ctx* ctx, int precision);
  * AFTER fiunet_set_options.  B=8 1080x1920: 6.4 GB bf16 / 12.8 GB fp32. */
 size_t fiunet_workspace_bytes(const fiunet_ctx* ctx, int B, int H, int W, int precision);
 
+/* Smallest batch B (1..64; 65 = none) at which NO layer of a forward of H x W frames cuts its K loop over several
+ * workgroups (see "Reproducibility" below): batches of at least that many pairs give every pair the same bits whatever
+ * the batch.  1 from 1080p up, 2 at 720p, > 8 for the reference's own 256x256.  Needs loaded weights (it walks the
+ * architecture); 0 on bad arguments.  Used by the video loops to pad a ragged last chunk no further than necessary.
+ * The reference has no counterpart (aten's conv results do depend on the batch in the last bit). */
+int fiunet_min_unsplit_batch(const fiunet_ctx* ctx, int H, int W, int precision);
+
 /* Replaces FrameInterpolationUNet.forward(frame1, frame2) in eval mode
  * (model/unet.py:105-112 -> :84-95), as called by interpolate_frames (model/inference.py:120).
  * frame1, frame2: device fp32 [B, frame_channels, H, W] contiguous (NCHW);

@@ -388,6 +388,31 @@ def test_sequence_result_does_not_depend_on_its_length_at_small_frames(model, de
     model.precision = "fp32"
 
 
+def test_ragged_chunks_are_padded_no_further_than_the_split_rule_needs(model, dev):
+    """`fiunet_min_unsplit_batch` is the library's own K-split rule: 1 from 1080p up (no layer ever splits), 2 at
+    720p (a single pair splits its deepest level), more than a batch at the reference's 256x256.  A one-pair 720p
+    clip is therefore computed as a batch of 2, not of 8 - and still equals the pair computed inside a full batch."""
+    for prec in ("fp32", "bf16", "bf16x2"):
+        model.precision = prec
+        assert model.batch_invariant_from(1080, 1920) == 1
+        assert model.batch_invariant_from(720, 1280) == 2
+        assert model.batch_invariant_from(256, 256) > 8
+    model.precision = "bf16"
+    fr = S.moving_frames(0, 9, 720, 1280, device=dev, seed=4)
+    calls = []
+    orig = model.forward_u8
+    model.forward_u8 = lambda a, b: (calls.append(a.shape[0]), orig(a, b))[1]
+    try:
+        full = P.interpolate_sequence(model, fr, batch=8)         # 8 pairs: one full batch
+        one = P.interpolate_sequence(model, fr[:2], batch=8)      # 1 pair -> padded to 2
+        three = P.interpolate_sequence(model, fr[:4], batch=8)    # 3 pairs -> as they are
+    finally:
+        del model.forward_u8
+    assert calls == [8, 2, 3], calls
+    assert torch.equal(one, full[:3]) and torch.equal(three, full[:7])
+    model.precision = "fp32"
+
+
 def test_frameinterpolator_y4m_video_in_and_out(model, dev, tmp_path):
     """`main.py video --input in --output out --factor 2` on a real (uncompressed) video container: luma
     through the network exactly as the .npy path, chroma of an inserted frame = rounded average of its
