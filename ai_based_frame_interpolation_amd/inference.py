@@ -133,14 +133,14 @@ def _pair_batches(n_pairs: int, batch: int):
 def _forward_u8_chunk(model, a: torch.Tensor, b: torch.Tensor, batch: int) -> torch.Tensor:
     """forward_u8 of one chunk of a sequence.  Below 1080p some layers of a forward have fewer workgroups
     than the chip has CUs and cut their K loop over several (split-K, fiunet.hip); how many depends on the
-    batch (at 720p a single pair still splits its deepest level, two or more do not), so the fp32 summation
+    batch (at 720p batches of fewer than five pairs still split the deepest level), so the fp32 summation
     order - hence a pixel sitting on a uint8 truncation boundary - of a pair may depend on how many pairs
     share its call.  A ragged chunk - the last one of a sequence, and the only one of a sequence shorter than
     a batch - is therefore padded (its last pair repeated, the extra outputs dropped) up to the smallest batch
-    at which no layer splits (`model.batch_invariant_from`, the library's own rule: 1 from 1080p up, 2 at 720p),
+    at which no layer splits (`model.batch_invariant_from`, the library's own rule: 1 from 1080p up, 5 at 720p),
     or to the full `batch` where even that still splits (256x256 at batch 8): every pair of a sequence is
     computed exactly as in a full batch, the result does not depend on the sequence length or on how the
-    sequence is sharded over ranks (`sequence_pair_fn`) - and a one-pair 720p clip costs 2 forwards, not 8."""
+    sequence is sharded over ranks (`sequence_pair_fn`) - and a one-pair 720p clip costs 5 forwards, not 8."""
     cnt = a.shape[0]
     target = cnt
     if cnt < batch:

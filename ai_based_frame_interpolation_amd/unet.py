@@ -305,7 +305,7 @@ class FrameInterpolationUNet(nn.Module):
 
     def batch_invariant_from(self, height: int, width: int, device=None) -> int:
         """Smallest batch at which the result of a pair no longer depends on the batch it is part of (no layer cuts
-        its K loop over workgroups: include/fiunet.h, fiunet_min_unsplit_batch).  1 from 1080p up, 2 at 720p."""
+        its K loop over workgroups: include/fiunet.h, fiunet_min_unsplit_batch).  1 from 1080p up, 5 at 720p."""
         dev = device if device is not None else next(self.parameters()).device
         return self._context(torch.device(dev)).min_unsplit_batch(int(height), int(width), self._precision_code())
 
