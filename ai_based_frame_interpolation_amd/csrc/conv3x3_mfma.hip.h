@@ -1415,6 +1415,11 @@ __global__ __launch_bounds__(256, conv_occupancy(BN, TH, TW)) void conv3x3_mfma_
     lds_dma_wait_all();
     __syncthreads();
     STAMP(1);
+#ifdef FIUNET_CLOCK
+    // diagnostic build (-DFIUNET_CLOCK, no other stamp executes): shader cycles (s_memtime) and constant 100 MHz ticks
+    // (s_memrealtime) ONCE around the K loop -> the clock this wave ran at (MI355X_MICROARCH.md, DVFS give-back item 6)
+    const unsigned long long ck_t0 = __builtin_amdgcn_s_memtime(), ck_r0 = __builtin_amdgcn_s_memrealtime();
+#endif
 
     int step = 0;
     int vj = X2 ? pbeg % 3 : 0;   // X2: piece combination of the current virtual plane
@@ -1518,6 +1523,19 @@ __global__ __launch_bounds__(256, conv_occupancy(BN, TH, TW)) void conv3x3_mfma_
         }
     }
 
+#ifdef FIUNET_CLOCK
+    {
+        asm volatile("" :: "v"(acc[3][NF - 1][3]));  // keep the stamp behind the last MFMA
+        __builtin_amdgcn_sched_barrier(0);
+        const unsigned long long ck_t1 = __builtin_amdgcn_s_memtime(), ck_r1 = __builtin_amdgcn_s_memrealtime();
+        if (a.stamp && lane == 0) {  // one private 64-B record per wave, read by nothing else in the kernel
+            unsigned long long* rec = a.stamp + ((size_t)blockIdx.x * 4 + wave) * 8;
+            rec[0] = ck_t1 - ck_t0;
+            rec[1] = ck_r1 - ck_r0;
+            rec[6] = 1ull;
+        }
+    }
+#endif
     conv_epilogue<T, BN, TH, TW, EPI, X2>(a, acc, b, y0, x0, ct, split, wc, wp, l15, lc);
 #ifdef FIUNET_STAMP
     STAMP(5);

@@ -728,6 +728,7 @@ int forward_x2(fiunet_ctx* ctx, const float* f1, const float* f2, float* out, in
         a.zero_page = ctx->zero_page;
         a.ksplit = 1;
         a.kslab = i == NCONV - 1 ? nullptr : (float*)(ws + p.slab_off);   // small problems: K-split like the other paths
+        a.stamp = (ctx->stamps && i == ctx->stamp_layer) ? ctx->stamps : nullptr;
         a.dst = act(i);
         a.src0 = act(kSrc0[i]);
         a.C0 = ctx->cout[kSrc0[i]];                // REAL channels: the kernel knows both pieces of a tensor
@@ -983,7 +984,7 @@ int fiunet_load_weights(fiunet_ctx* ctx, int n, const char* const* names,
         if ((rc = dev_upload(ctx, bi, (size_t)ctx->cf * 4, (void**)&ctx->head_b))) return rc;
         const std::vector<char> zeros(256, 0);
         if ((rc = dev_upload(ctx, zeros.data(), zeros.size(), &ctx->zero_page))) return rc;
-#ifdef FIUNET_STAMP
+#if defined(FIUNET_STAMP) || defined(FIUNET_CLOCK)
         {   // one 64-B record per wave of the largest launch (B=8 1080p: 32 640 workgroups)
             void* d = nullptr;
             HIP_TRY(hipMalloc(&d, kStampWaves * 64));
@@ -1313,7 +1314,7 @@ int fiunet_postprocess_u8(const float* in, uint8_t* out, size_t n, void* stream)
     return FIUNET_OK;
 }
 
-#ifdef FIUNET_STAMP
+#if defined(FIUNET_STAMP) || defined(FIUNET_CLOCK)
 // diagnostic builds only (not part of the ABI): stamp ONE stage per forward; read = sums over waves
 int fiunet_debug_stamp_layer(fiunet_ctx* ctx, int layer)
 {
@@ -1331,6 +1332,14 @@ int fiunet_debug_stamps(fiunet_ctx* ctx, unsigned long long* out /* [8] */)
     for (size_t w = 0; w < kStampWaves; ++w)
         for (int k = 0; k < 8; ++k) out[k] += h[w * 8 + k];
     return FIUNET_OK;
+}
+// the raw per-wave records ([kStampWaves][8] u64; record[6] != 0 where a wave wrote); returns the record count
+int fiunet_debug_stamp_records(fiunet_ctx* ctx, unsigned long long* out, size_t max_records)
+{
+    HIP_TRY(hipDeviceSynchronize());
+    const size_t n = std::min(max_records, kStampWaves);
+    HIP_TRY(hipMemcpy(out, ctx->stamps, n * 64, hipMemcpyDeviceToHost));
+    return (int)n;
 }
 #endif
 

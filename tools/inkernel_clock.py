@@ -1,0 +1,49 @@
+"""In-kernel clock of the conv stages (review item 5; MI355X_MICROARCH.md, DVFS give-back item 6): a -DFIUNET_CLOCK
+build stamps s_memtime (shader cycles) and s_memrealtime (constant 100 MHz) ONCE around the K loop of every wave of ONE
+stage per forward; clock = d(memtime) / d(memrealtime) x 100 MHz, median over the waves, after >= 2 s of back-to-back
+forwards on random data.  Also the wall time of the stage in the same forward (HIP events), so that
+    executed bf16 MFMA rate = 3^x2 x algorithmic FLOPs / time   and   MFMA-busy = that / (1024 FLOP/cycle/SIMD x 1024 SIMDs x clock)
+    FIUNET_LIB=ablibs/lib_clock.so python tools/inkernel_clock.py [B H W precision]"""
+import ctypes, os, statistics, sys, time
+import numpy as np, torch
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT)
+import bench
+from ai_based_frame_interpolation_amd import _native
+b, h, w = (int(v) for v in sys.argv[1:4]) if len(sys.argv) > 3 else (8, 1080, 1920)
+prec = sys.argv[4] if len(sys.argv) > 4 else "bf16"
+dev = torch.device("cuda:0")
+m = bench.make_bench_model(prec).to(dev).eval()
+g = torch.Generator(device=dev).manual_seed(1)
+f1 = torch.rand(b, 1, h, w, device=dev, generator=g) * 2 - 1
+f2 = torch.rand(b, 1, h, w, device=dev, generator=g) * 2 - 1
+m(f1, f2)
+L = _native.lib()
+L.fiunet_debug_stamp_layer.argtypes = [ctypes.c_void_p, ctypes.c_int]
+L.fiunet_debug_stamp_records.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t]
+NREC = 4 * 40000
+buf = np.zeros((NREC, 8), dtype=np.uint64)
+t0 = time.time()
+while time.time() - t0 < 2.5:      # >= 2 s of back-to-back forwards before the first stamp (the chip settles its clock)
+    for _ in range(10): m(f1, f2)
+    torch.cuda.synchronize()
+mult = 3.0 if prec == "bf16x2" else 1.0
+print(f"# in-kernel clock per stage, B={b} {w}x{h} {prec}: d(s_memtime)/d(s_memrealtime) x 100 MHz around the K loop, median over waves")
+print(f"{'stage':>5} {'ms':>7} {'alg TF/s':>9} {'exec TF/s':>9} {'GHz med':>8} {'p10':>6} {'p90':>6} {'busy':>6} {'busy x GHz':>10} {'frac of peak at that clock':>10}  kernel")
+for i in range(1, 18):
+    for _ in range(6): m(f1, f2)               # keep the load on between stages
+    L.fiunet_debug_stamp_layer(m._ctx._h, i)   # (synchronises, clears the records)
+    for _ in range(3): m(f1, f2)               # the records of the last forward stay
+    m._ctx.profile_enable(True)
+    m(f1, f2)
+    n, rows = m._ctx.profile_read(); m._ctx.profile_enable(False)
+    L.fiunet_debug_stamp_records(m._ctx._h, buf.ctypes.data_as(ctypes.c_void_p), NREC)
+    ok = (buf[:, 6] != 0) & (buf[:, 1] > 0)
+    ghz = buf[ok, 0].astype(np.float64) / buf[ok, 1].astype(np.float64) * 0.1
+    name, ms, fl = rows[i]
+    if not ok.any() or ms <= 0:
+        print(f"{i:5d}  (no records: {name})"); continue
+    med, p10, p90 = np.median(ghz), np.percentile(ghz, 10), np.percentile(ghz, 90)
+    alg = fl / (ms * 1e-3) / 1e12
+    ex = alg * mult
+    busy = ex * 1e12 / (1024 * 1024 * med * 1e9)     # 16x16x32 bf16: 16384 FLOP in 16 cycles on each of 1024 SIMDs
+    print(f"{i:5d} {ms:7.3f} {alg:9.1f} {ex:9.1f} {med:8.3f} {p10:6.3f} {p90:6.3f} {busy:6.3f} {busy * med:10.3f} {ex / (2500.0 * med / 2.4):10.3f}  {name}")
