@@ -17,7 +17,15 @@ align_corners=True, i.e. with a scale that depends on the WHOLE image's size.  H
 Multi-GPU: one process per GPU, rank r computes band r.  The only traffic is the scatter of the
 input bands (+halo) from the rank that holds the frames and the gather of the output bands, as
 point-to-point send/recv (RCCL over the direct xGMI links on GPUs, gloo in the CPU tests); there is
-no collective and no exchange inside the forward.
+no collective and no exchange inside the forward.  There is NO neighbour-to-neighbour halo exchange
+(SURVEY 8e option A): the halo is input, cut from the root's copy of the frames.
+
+Wire format: the dtype of the frames.  Video frames are uint8 (`wire=torch.uint8`, SURVEY 8e "keep frames
+uint8 on the wire"): bands travel as uint8 - a quarter of the fp32 bytes in both directions - and every
+rank applies the reference's pre/post-processing (model/inference.py:31-35, :54-61) on its own device
+around its band, so the assembled uint8 frame equals `model.forward_u8` of the whole pair bit for bit.
+fp32 tensors (`wire=torch.float32`, the default) travel as they are: any narrower float on the wire would
+change the input of the network.
 """
 from __future__ import annotations
 
@@ -62,6 +70,19 @@ def strip_plan(height: int, n_strips: int, halo: int = HALO) -> List[Strip]:
 StripFn = Callable[[torch.Tensor, torch.Tensor, int, int], torch.Tensor]
 
 
+def u8_strip_fn(strip_fn: StripFn, pre=None, post=None) -> StripFn:
+    """`strip_fn` on uint8 bands: device pre-processing -> fp32 strip forward -> device post-processing
+    (the kernels behind `fiunet_preprocess_u8` / `fiunet_postprocess_u8`; `pre` / `post` replace them in the
+    CPU tests, which have no device)."""
+    if pre is None or post is None:
+        from . import _native
+        pre, post = pre or _native.preprocess_u8, post or _native.postprocess_u8
+
+    def fn(a, b, y_origin, image_height):
+        return post(strip_fn(pre(a), pre(b), y_origin, image_height))
+    return fn
+
+
 def forward_tiled(strip_fn: StripFn, frame1: torch.Tensor, frame2: torch.Tensor, n_strips: int,
                   halo: int = HALO) -> torch.Tensor:
     """All strips on this device, one after the other (bounds the workspace of a huge frame to one
@@ -84,10 +105,19 @@ def _p2p(ops):
 
 def forward_tiled_distributed(strip_fn: StripFn, frame1: Optional[torch.Tensor],
                               frame2: Optional[torch.Tensor], shape, device, root: int = 0,
-                              halo: int = HALO, group=None) -> Optional[torch.Tensor]:
-    """Rank `root` holds the fp32 pair `[B, C, H, W]` (`shape`); rank r computes strip r of
-    world_size strips; `root` returns the assembled `[B, C, H, W]` output, the others None."""
+                              halo: int = HALO, group=None, wire: torch.dtype = torch.float32,
+                              pre=None, post=None) -> Optional[torch.Tensor]:
+    """Rank `root` holds the pair `[B, C, H, W]` (`shape`) in dtype `wire`; rank r computes strip r of
+    world_size strips; `root` returns the assembled `[B, C, H, W]` output (dtype `wire`), the others None.
+    wire = torch.uint8: uint8 frames in, uint8 frame out, uint8 on the wire (see the module docstring);
+    `strip_fn` is still the fp32 `forward_strip`."""
     rank, world = dist.get_rank(group), dist.get_world_size(group)
+    if wire not in (torch.float32, torch.uint8):
+        raise ValueError("wire must be torch.float32 or torch.uint8")
+    if rank == root and (frame1.dtype != wire or frame2.dtype != wire):
+        raise ValueError(f"root's frames are {frame1.dtype} / {frame2.dtype}, wire is {wire}")
+    if wire == torch.uint8:
+        strip_fn = u8_strip_fn(strip_fn, pre, post)
     b, c, h, w = shape
     plan = strip_plan(h, world, halo)
     mine = plan[rank]
@@ -102,7 +132,7 @@ def forward_tiled_distributed(strip_fn: StripFn, frame1: Optional[torch.Tensor],
         f1 = frame1[..., mine.ext0:mine.ext1, :].contiguous()
         f2 = frame2[..., mine.ext0:mine.ext1, :].contiguous()
     elif mine.core1 > mine.core0:
-        f1 = torch.empty((b, c, mine.ext1 - mine.ext0, w), dtype=torch.float32, device=device)
+        f1 = torch.empty((b, c, mine.ext1 - mine.ext0, w), dtype=wire, device=device)
         f2 = torch.empty_like(f1)
         _p2p([dist.P2POp(dist.irecv, f1, root, group), dist.P2POp(dist.irecv, f2, root, group)])
     # 2. this rank's band
@@ -115,7 +145,7 @@ def forward_tiled_distributed(strip_fn: StripFn, frame1: Optional[torch.Tensor],
         if core is not None:
             _p2p([dist.P2POp(dist.isend, core, root, group)])
         return None
-    out = torch.empty((b, c, h, w), dtype=torch.float32, device=device)
+    out = torch.empty((b, c, h, w), dtype=wire, device=device)
     ops, bufs = [], []
     for r, s in enumerate(plan):
         if s.core1 <= s.core0:
@@ -123,7 +153,7 @@ def forward_tiled_distributed(strip_fn: StripFn, frame1: Optional[torch.Tensor],
         if r == root:
             out[..., s.core0:s.core1, :] = core
         else:
-            buf = torch.empty((b, c, s.core1 - s.core0, w), dtype=torch.float32, device=device)
+            buf = torch.empty((b, c, s.core1 - s.core0, w), dtype=wire, device=device)
             bufs.append((s, buf))
             ops.append(dist.P2POp(dist.irecv, buf, r, group))
     _p2p(ops)

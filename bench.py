@@ -30,8 +30,10 @@ Extra objects on that line:
   video_sharded -- BASELINE configs[3]: a synthetic 1080p uint8 video held by rank 0, factor 2,
                    end to end through video.interpolate_video_sharded (RCCL send/recv scatter of
                    frame sub-batches, forward_u8, gather), beside the replicas-only `value`.
-  tile4k        -- BASELINE configs[4] (N >= 2): one 2160x3840 pair cut into N row bands + halo
-                   through tiling.forward_tiled_distributed.
+  tile4k        -- BASELINE configs[4]: N >= 2: one 2160x3840 uint8 pair cut into N row bands + halo through
+                   tiling.forward_tiled_distributed (uint8 on the wire); N = 1: the un-tiled pair, the four
+                   config-5 bands each and back to back, tiled == un-tiled.
+                   video_sharded also carries the HOST-resident (PCIe-inclusive) rate at N = 1.
 The oracle is only the baseline/checker here; the measured path never touches it.
 """
 from __future__ import annotations
@@ -350,8 +352,35 @@ def video_leg(model, dev, dist, rank, world, n_frames, batch, h, w):
         seen = dist.get_world_size()
     else:
         pairs_per_rank = [n_frames - 1]
+    host = None
+    if dist is None:
+        # PCIe-inclusive rate of the same job (N = 1): the frames start in HOST memory and the result ends there -
+        # pinned buffers, chunks double-buffered on a copy stream against the compute stream
+        # (inference.interpolate_sequence_host).  Never `value`; reported beside the device-resident number.
+        try:
+            t0 = time.perf_counter()
+            src = frames.cpu().pin_memory()
+            obuf = torch.empty((2 * n_frames - 1, h, w), dtype=torch.uint8).pin_memory()
+            t_pin = time.perf_counter() - t0
+            P.interpolate_sequence_host(model, src[:min(n_frames, 2 * batch + 1)], batch=batch)   # warm-up
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            hout = P.interpolate_sequence_host(model, src, batch=batch, out=obuf)
+            torch.cuda.synchronize()
+            th = time.perf_counter() - t0
+            same = all(bool(torch.equal(hout[k], res[k].cpu())) for k in (1, n_frames | 1, 2 * n_frames - 3))
+            host = {"interpolated_frames_per_s": round((n_frames - 1) / th, 2), "seconds": round(th, 4),
+                    "pcie_bytes_per_interpolated_frame": 2 * h * w,
+                    "pin_and_stage_seconds_not_timed": round(t_pin, 2),
+                    "equal_to_device_resident_result": same,
+                    "note": "host uint8 frames -> host uint8 result, pinned, H2D / D2H on a copy stream under the forwards"}
+            del src, obuf, hout
+        except Exception as e:  # noqa: BLE001 -- an extra: report it, keep the leg
+            host = {"error": f"{type(e).__name__}: {e}"}
     return {"frames_in": n_frames, "frames_out": 2 * n_frames - 1, "seconds": round(dt, 4),
-            "interpolated_frames_per_s": round((n_frames - 1) / dt, 2), "ranks": seen,
+            "interpolated_frames_per_s": round((n_frames - 1) / dt, 2),
+            "host_resident_frames_per_s": None if host is None else host.get("interpolated_frames_per_s"),
+            "host_resident": host, "ranks": seen,
             "pairs_per_rank": pairs_per_rank,
             "backend": ("single process" if dist is None else
                         "rccl (torch.distributed nccl) send/recv" if dist.get_backend() == "nccl" else
@@ -360,8 +389,52 @@ def video_leg(model, dev, dist, rank, world, n_frames, batch, h, w):
             "note": "end to end: frames resident in rank 0's HBM -> interleaved uint8 result in rank 0's HBM"}
 
 
+def tile4k_single_gpu_leg(model, dev, reps=10):
+    """BASELINE configs[4] as far as ONE GPU can measure it: one 2160x3840 pair un-tiled, the four config-5 row
+    bands (origins 0 / 544 / 1088 / 1632, + 112-row halo) each on its own - what one of four GPUs would spend on its
+    band, the bands being independent forwards - and back to back, and whether tiled == un-tiled."""
+    from ai_based_frame_interpolation_amd import tiling as T
+
+    torch.cuda.set_device(dev)
+    h, w, n = 2160, 3840, 4
+    gen = torch.Generator(device=dev).manual_seed(5)
+    f1 = torch.rand((1, 1, h, w), device=dev, generator=gen) * 2 - 1
+    f2 = torch.rand((1, 1, h, w), device=dev, generator=gen) * 2 - 1
+
+    def timeit(fn, k=reps, warm=2):
+        for _ in range(warm):
+            fn()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(k):
+            fn()
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / k * 1e3
+
+    whole = model(f1, f2)
+    t_whole = timeit(lambda: model(f1, f2))
+    tiled = T.forward_tiled(model.forward_strip, f1, f2, n)
+    equal = bool(torch.equal(tiled, whole))
+    t_all = timeit(lambda: T.forward_tiled(model.forward_strip, f1, f2, n), k=max(3, reps // 2))
+    bands = []
+    for s in T.strip_plan(h, n):
+        a = f1[..., s.ext0:s.ext1, :].contiguous()
+        b = f2[..., s.ext0:s.ext1, :].contiguous()
+        bands.append({"rows": [s.core0, s.core1], "rows_with_halo": [s.ext0, s.ext1],
+                      "ms": round(timeit(lambda: model.forward_strip(a, b, s.ext0, h)), 3),
+                      "wire_mb_uint8": round((2 * a.numel() + (s.core1 - s.core0) * w) / 1e6, 1)})
+    slow = max(bd["ms"] for bd in bands)
+    return {"untiled_ms_per_pair": round(t_whole, 3), "untiled_pairs_per_s": round(1e3 / t_whole, 1),
+            "bands": bands, "four_bands_back_to_back_ms": round(t_all, 3),
+            "recompute_factor": round(t_all / t_whole, 3), "tiled_equals_untiled_bitwise": equal,
+            "slowest_band_ms": slow, "latency_bound_if_4_gpus_ms": slow, "precision": model.precision,
+            "halo_rows": T.HALO,
+            "note": "ONE GPU: band times are what each of four GPUs would compute; no transfer is timed here "
+                    "(one-shot input halo from the root, no neighbour exchange: DESIGN section 7)"}
+
+
 def tile4k_leg(model, dev, dist, rank, world, reps):
-    """BASELINE configs[4]: one 2160x3840 pair, `world` row bands + 112-row halo."""
+    """BASELINE configs[4]: one 2160x3840 pair, `world` row bands + 112-row halo; uint8 frames, uint8 on the wire."""
     from ai_based_frame_interpolation_amd import tiling as T
 
     torch.cuda.set_device(dev)
@@ -370,11 +443,11 @@ def tile4k_leg(model, dev, dist, rank, world, reps):
     f1 = f2 = None
     if rank == 0:
         gen = torch.Generator(device=dev).manual_seed(5)
-        f1 = torch.rand(shape, device=dev, generator=gen) * 2 - 1
-        f2 = torch.rand(shape, device=dev, generator=gen) * 2 - 1
+        f1 = torch.randint(0, 256, shape, device=dev, generator=gen, dtype=torch.uint8)
+        f2 = torch.randint(0, 256, shape, device=dev, generator=gen, dtype=torch.uint8)
 
     def once():
-        return T.forward_tiled_distributed(model.forward_strip, f1, f2, shape, dev, root=0)
+        return T.forward_tiled_distributed(model.forward_strip, f1, f2, shape, dev, root=0, wire=torch.uint8)
 
     for _ in range(2):
         out = once()
@@ -385,17 +458,17 @@ def tile4k_leg(model, dev, dist, rank, world, reps):
     dist.barrier(); torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / reps
     res = {"ms_per_pair": round(dt * 1e3, 3), "pairs_per_s": round(1.0 / dt, 2), "strips": world,
-           "halo_rows": T.HALO, "precision": model.precision}
+           "halo_rows": T.HALO, "precision": model.precision, "wire": "uint8 bands (input halo from the root), uint8 result"}
     if rank == 0:
-        whole = model(f1, f2)
+        whole = model.forward_u8(f1, f2)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         for _ in range(reps):
-            whole = model(f1, f2)
+            whole = model.forward_u8(f1, f2)
         torch.cuda.synchronize()
         res["untiled_one_gpu_ms"] = round((time.perf_counter() - t0) / reps * 1e3, 3)
         res["tiled_equals_untiled_bitwise"] = bool(torch.equal(out, whole))
-        res["tiled_vs_untiled_max_abs"] = float((out - whole).abs().max())
+        res["tiled_vs_untiled_max_abs"] = int((out.int() - whole.int()).abs().max())
     return res
 
 
@@ -562,6 +635,11 @@ def main():
                                               video_res, None, None, None)))
                     sys.stdout.flush()
                 os._exit(3)  # the headline is printed, but a hung leg must show in the return code
+    if world == 1 and default_workload and not args.no_tile4k:
+        with _quiet_native_stdout():
+            tile_res, err = _run_bounded(lambda: tile4k_single_gpu_leg(model, dev), 120.0)
+        if err:
+            tile_res = {"error": err, "strips": 4}
     if dist is not None and world >= 2 and default_workload and not args.no_tile4k:
         with _quiet_native_stdout():
             tile_res, err = _run_bounded(lambda: tile4k_leg(model, dev, dist, rank, world, 10), 120.0)

@@ -135,6 +135,14 @@ def test_forward_tiled_single_process(h, n):
     assert torch.equal(got, want)
 
 
+def _cpu_pre(u):    # model/inference.py:31-35
+    return 2.0 * (u.to(torch.float32) / 255.0) - 1.0
+
+
+def _cpu_post(x):   # model/inference.py:54-61 (truncating cast)
+    return (torch.clamp((x + 1.0) / 2.0, 0.0, 1.0) * 255.0).to(torch.uint8)
+
+
 def _tile_worker(rank, world, port, h, q):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
@@ -146,10 +154,22 @@ def _tile_worker(rank, world, port, h, q):
         f2 = torch.rand(shape, generator=g)
         out = tiling.forward_tiled_distributed(_box_strip_fn, f1 if rank == 0 else None,
                                                f2 if rank == 0 else None, shape, torch.device("cpu"))
+        # the video form: uint8 frames, uint8 bands on the wire, pre/post-processing on every rank's own band
+        u1 = torch.randint(0, 256, shape, dtype=torch.uint8, generator=g)
+        u2 = torch.randint(0, 256, shape, dtype=torch.uint8, generator=g)
+        sent = []
+        orig = tiling._p2p
+        tiling._p2p = lambda ops: (sent.extend(o.tensor.dtype for o in ops), orig(ops))[1]
+        out8 = tiling.forward_tiled_distributed(_box_strip_fn, u1 if rank == 0 else None, u2 if rank == 0 else None,
+                                                shape, torch.device("cpu"), wire=torch.uint8, pre=_cpu_pre, post=_cpu_post)
+        tiling._p2p = orig
+        assert all(d == torch.uint8 for d in sent) and (sent or h == 16), sent     # only bytes travel (h = 16: one band, no traffic)
         if rank == 0:
-            q.put(bool(torch.equal(out, _box_strip_fn(f1, f2, 0, h))))
+            want8 = _cpu_post(_box_strip_fn(_cpu_pre(u1), _cpu_pre(u2), 0, h))
+            q.put(bool(torch.equal(out, _box_strip_fn(f1, f2, 0, h))) and out8.dtype == torch.uint8
+                  and bool(torch.equal(out8, want8)))
         else:
-            assert out is None
+            assert out is None and out8 is None
     finally:
         dist.destroy_process_group()
 
