@@ -27,6 +27,8 @@ while time.time() - t0 < 2.5:      # >= 2 s of back-to-back forwards before the 
     for _ in range(10): m(f1, f2)
     torch.cuda.synchronize()
 mult = 3.0 if prec == "bf16x2" else 1.0
+jout = sys.argv[5] if len(sys.argv) > 5 else None
+recs = []
 print(f"# in-kernel clock per stage, B={b} {w}x{h} {prec}: d(s_memtime)/d(s_memrealtime) x 100 MHz around the K loop, median over waves")
 print(f"{'stage':>5} {'ms':>7} {'alg TF/s':>9} {'exec TF/s':>9} {'GHz med':>8} {'p10':>6} {'p90':>6} {'busy':>6} {'busy x GHz':>10} {'frac of peak at that clock':>10}  kernel")
 for i in range(1, 18):
@@ -47,3 +49,11 @@ for i in range(1, 18):
     ex = alg * mult
     busy = ex * 1e12 / (1024 * 1024 * med * 1e9)     # 16x16x32 bf16: 16384 FLOP in 16 cycles on each of 1024 SIMDs
     print(f"{i:5d} {ms:7.3f} {alg:9.1f} {ex:9.1f} {med:8.3f} {p10:6.3f} {p90:6.3f} {busy:6.3f} {busy * med:10.3f} {ex / (2500.0 * med / 2.4):10.3f}  {name}")
+    recs.append({"stage": i, "kernel": name, "ms": round(ms, 4), "ghz_median": round(float(med), 4), "ghz_p10": round(float(p10), 4),
+                 "ghz_p90": round(float(p90), 4), "useful_mfma_busy": round(float(busy), 4)})
+if jout:
+    import json, datetime
+    json.dump({"_meta": {"workload": f"B={b} {w}x{h} {prec}", "date": datetime.date.today().isoformat(),
+                         "method": "s_memtime / s_memrealtime x 100 MHz around the K loop, -DFIUNET_CLOCK build, median over waves, "
+                                   "after 2.5 s of back-to-back forwards (tools/inkernel_clock.py)"},
+               "stages": recs}, open(jout, "w"), indent=1)
