@@ -230,11 +230,18 @@ __device__ __forceinline__ uint4 chunk_bilerp(const uint4& a, const uint4& b, co
 template <typename T>
 __device__ __forceinline__ void chunk_hlerp(const uint4& a, const uint4& b, float hx, float lx, float* h)
 {
-    constexpr int NE = Elem<T>::NE;
+    [[maybe_unused]] constexpr int NE = Elem<T>::NE;
+#ifdef FIUNET_DIAG_NO_HLERP
+    // timing diagnostic (results are garbage): what the consumer's gather would cost if the HORIZONTAL lerp had been
+    // done by the producer (review item 6): one staged chunk per low-res row, unpacked, no arithmetic
+    (void)b; (void)hx; (void)lx;
+    chunk_unpack<T>(a, h);
+#else
     float fa[NE], fb[NE];
     chunk_unpack<T>(a, fa); chunk_unpack<T>(b, fb);
 #pragma unroll
     for (int i = 0; i < NE; ++i) h[i] = fmaf(lx, fb[i], __fmul_rn(hx, fa[i]));
+#endif
 }
 template <typename T>
 __device__ __forceinline__ uint4 chunk_vlerp(const float* top, const float* bot, float hy, float ly)

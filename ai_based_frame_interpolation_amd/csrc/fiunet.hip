@@ -527,7 +527,9 @@ int forward_impl(fiunet_ctx* ctx, const float* f1, const float* f2, float* out, 
             // the RGB bf16 network stay bit-identical fused vs unfused); the fp32 network keeps the exact kernel
             if constexpr (sizeof(T) == 2) {
                 const long long ntiles = (long long)B * ((H + 15) / 16) * ((W + 31) / 32);
-                dim3 g2((unsigned)std::min<long long>(ntiles, 256 * 4));
+                // persistent workgroups, one tile after the other: exactly as many as are resident at once (153 registers
+                // -> 3 waves per SIMD -> 3 workgroups per CU); with 1024 the last 256 ran a second round on a third of the chip
+                dim3 g2((unsigned)std::min<long long>(ntiles, 256 * FIUNET_RGB_STEM_OCC));
                 hipLaunchKernelGGL(stem_rgb_split_kernel, g2, dim3(256), 0, s, f1, f2, (const float*)cw.w_f32, cw.scale,
                                    cw.shift, (__bf16*)act(0), B, H, W, stem_dither_amp, u1, u2);
                 stem_split_rgb = true;

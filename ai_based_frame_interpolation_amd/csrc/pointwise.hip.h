@@ -176,7 +176,10 @@ __global__ __launch_bounds__(256) void conv3x3_first_kernel(
 // are empty - 9 bf16 MFMAs of 16 cycles per cout tile instead of 14 fp32 ones of 32.  Same scheme, and the same
 // ~2^-16 relative accuracy before the bf16 rounding of the output, as the fused gray stem (conv3x3_mfma.hip.h,
 // SRC_STEM).  /root/reference/model/unet.py:72 with n_channels = 6 (unet.py:66); channel order of torch.cat([f1, f2]).
-__global__ __launch_bounds__(256) void stem_rgb_split_kernel(
+#ifndef FIUNET_RGB_STEM_OCC
+#define FIUNET_RGB_STEM_OCC 2
+#endif
+__global__ __launch_bounds__(256, FIUNET_RGB_STEM_OCC) void stem_rgb_split_kernel(
     const float* __restrict__ f1, const float* __restrict__ f2, const float* __restrict__ w,  // w: [9 taps][6][64] fp32
     const float* __restrict__ scale, const float* __restrict__ shift, __bf16* __restrict__ dst, int B, int H, int W,
     float dither, const uint8_t* __restrict__ u1, const uint8_t* __restrict__ u2)
@@ -185,7 +188,8 @@ __global__ __launch_bounds__(256) void stem_rgb_split_kernel(
     // (preprocess_u8_value: the same fp32 values fiunet_preprocess_u8 would have written), f1 / f2 are unused
     constexpr int CF = 3, TH = 16, TW = 32, PH = TH + 2, PW = TW + 4;
     constexpr int IMG = PH * PW;                 // dwords of one (colour, hi | lo) patch image
-    constexpr int BIAS_OFF = 6 * IMG;            // 8 dwords {1.0, 0}, 0, 0, ... (hi operand of the bias k-group)
+    constexpr int BUF = 6 * IMG;                 // one patch buffer: 3 colours x (hi, lo); there are two (double-buffered)
+    constexpr int BIAS_OFF = 2 * BUF;            // 8 dwords {1.0, 0}, 0, 0, ... (hi operand of the bias k-group)
     constexpr int ZERO_OFF = BIAS_OFF + 8;       // 8 zero dwords (its lo operand; both operands of the empty groups)
     __shared__ __attribute__((aligned(16))) unsigned pd[ZERO_OFF + 8];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -228,33 +232,66 @@ __global__ __launch_bounds__(256) void stem_rgb_split_kernel(
     const int tilesX = (W + TW - 1) / TW, tilesY = (H + TH - 1) / TH;
     const long long ntiles = (long long)B * tilesX * tilesY;
     const size_t plane = (size_t)H * W;
-    for (long long t = blockIdx.x; t < ntiles; t += gridDim.x) {
+    // The raw patch of the NEXT tile is requested (into registers) before this tile's fragments run and converted /
+    // split / stored into the other of two LDS patch buffers after them: the global round trip of a tile's 18 loads per
+    // thread hides under the previous tile's MFMAs, and a tile costs one barrier (round 4 staged and multiplied in turn).
+    constexpr int NI = (IMG + 255) / 256;        // patch pixels per thread
+    float r0[NI][CF], r1[NI][CF], dth[NI];
+    unsigned okm = 0;
+    auto fetch = [&](long long t) __attribute__((always_inline)) {
         const int tx = (int)(t % tilesX);
         const long long q = t / tilesX;
         const int ty = (int)(q % tilesY), b = (int)(q / tilesY);
         const int y0 = ty * TH, x0 = tx * TW;
-        __syncthreads();   // the previous tile's fragment reads are done (and the bias / zero rows are written)
-        // ---- patch: one thread per patch pixel and pass; clamped unconditional loads, zero outside the image
-        for (int i = tid; i < IMG; i += 256) {
+        okm = 0;
+#pragma unroll
+        for (int k = 0; k < NI; ++k) {
+            const int i = tid + k * 256;
             const int py = i / PW, px = i - py * PW;
             const int y = y0 - 1 + py, x = x0 - 1 + px;
-            const bool ok = (y >= 0) & (y < H) & (x >= 0) & (x < W);
+            const bool ok = (i < IMG) & (y >= 0) & (y < H) & (x >= 0) & (x < W);
+            okm |= (ok ? 1u : 0u) << k;
             const size_t at = (size_t)min(max(y, 0), H - 1) * W + min(max(x, 0), W - 1);
-            const float d = dither * stem_dither(y, x);
+            dth[k] = dither * stem_dither(y, x);
 #pragma unroll
             for (int c = 0; c < CF; ++c) {
                 const size_t idx = ((size_t)b * CF + c) * plane + at;
-                float v0, v1;
-                if (u1) { v0 = preprocess_u8_value(u1[idx]); v1 = preprocess_u8_value(u2[idx]); }   // wave-uniform
-                else { v0 = f1[idx]; v1 = f2[idx]; }
-                v0 = ok ? v0 + d : 0.f;   // +d on frame 1, -d on frame 2; the conv's zero padding stays exactly zero
-                v1 = ok ? v1 - d : 0.f;
-                const unsigned hi = pack_bf16x2_pk(v0, v1);
-                pd[(c * 2) * IMG + i] = hi;
-                pd[(c * 2 + 1) * IMG + i] = pack_bf16x2_pk(v0 - __uint_as_float(hi << 16), v1 - __uint_as_float(hi & 0xffff0000u));
+                if (u1) { r0[k][c] = (float)u1[idx]; r1[k][c] = (float)u2[idx]; }   // wave-uniform; converted in stash()
+                else { r0[k][c] = f1[idx]; r1[k][c] = f2[idx]; }
             }
         }
-        __syncthreads();
+    };
+    auto stash = [&](unsigned* dst) __attribute__((always_inline)) {
+#pragma unroll
+        for (int k = 0; k < NI; ++k) {
+            const int i = tid + k * 256;
+            const bool ok = (okm >> k) & 1u;
+#pragma unroll
+            for (int c = 0; c < CF; ++c) {
+                float v0 = r0[k][c], v1 = r1[k][c];
+                if (u1) { v0 = preprocess_u8_value((unsigned char)v0); v1 = preprocess_u8_value((unsigned char)v1); }
+                v0 = ok ? v0 + dth[k] : 0.f;   // +d on frame 1, -d on frame 2; the conv's zero padding stays exactly zero
+                v1 = ok ? v1 - dth[k] : 0.f;
+                const unsigned hi = pack_bf16x2_pk(v0, v1);
+                if (i < IMG) {
+                    dst[(c * 2) * IMG + i] = hi;
+                    dst[(c * 2 + 1) * IMG + i] = pack_bf16x2_pk(v0 - __uint_as_float(hi << 16), v1 - __uint_as_float(hi & 0xffff0000u));
+                }
+            }
+        }
+    };
+    long long t = blockIdx.x;
+    if (t < ntiles) fetch(t);
+    int buf = 0;
+    for (; t < ntiles; t += gridDim.x, buf ^= 1) {
+        const int tx = (int)(t % tilesX);
+        const long long q = t / tilesX;
+        const int ty = (int)(q % tilesY), b = (int)(q / tilesY);
+        const int y0 = ty * TH, x0 = tx * TW;
+        unsigned* const pb = pd + buf * BUF;
+        stash(pb);
+        __syncthreads();   // this tile's patch is complete; every wave is past the fragments of the tile before last (same buffer)
+        if (t + gridDim.x < ntiles) fetch(t + gridDim.x);
         // ---- fragments: wave = 4 tile rows x 2 column halves
 #pragma unroll 2
         for (int f = 0; f < 8; ++f) {
@@ -265,7 +302,7 @@ __global__ __launch_bounds__(256) void stem_rgb_split_kernel(
             for (int ct = 0; ct < 4; ++ct) acc[ct] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int ch = 0; ch < 3; ++ch) {
-                const unsigned o = fmul[ch] * (unsigned)(r * PW + xc);
+                const unsigned o = fmul[ch] * (unsigned)(r * PW + xc + buf * BUF);
                 const unsigned* ph = pd + off_h[ch] + o;
                 const unsigned* pl = pd + off_l[ch] + o;
                 const uint4 bh = make_uint4(ph[0], ph[1], ph[2], ph[3]);
