@@ -13,11 +13,14 @@ for r in range(rounds):
         env = dict(os.environ)
         if p != "default":
             env["FIUNET_LIB"] = os.path.join(ROOT, p)
-        out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "stage_times.py"), *shape, prec, "1", "8"],
-                             env=env, capture_output=True, text=True).stdout
+        run = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "stage_times.py"), *shape, prec, "1", "8"],
+                             env=env, capture_output=True, text=True)
+        out = run.stdout
+        if run.returncode != 0 or "core dump" in (run.stdout + run.stderr).lower():
+            print(n, "FAILED rc", run.returncode, (run.stdout + run.stderr)[-400:]); sys.exit(1)
         m = re.search(r"([\d.]+) frames/s", out)
-        if not m:
-            print(n, "FAILED", out[-300:]); continue
+        if not m:   # a failed arm (possibly a GPU fault): stop at once, never launch another GPU process after it
+            print(n, "FAILED", out[-300:]); sys.exit(1)
         fps[n].append(float(m.group(1))); last[n] = out
         print(f"round {r} {n}: {m.group(1)} frames/s", flush=True)
 for n in fps:
