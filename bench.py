@@ -338,10 +338,10 @@ def video_leg(model, dev, dist, rank, world, n_frames, batch, h, w):
     sync()
     dt = time.perf_counter() - t0
     ok = None
-    if rank == 0:  # spot-check three pairs against the single-GPU uint8 forward
-        ok = True
+    if rank == 0:  # spot-check three pairs against the single-GPU uint8 forward (through the same chunk helper: below
+        ok = True  # 1080p a lone pair is padded to the batch at which no layer K-splits, as the loops pad theirs)
         for i in (0, (n_frames - 1) // 2, n_frames - 2):
-            mid = model.forward_u8(frames[i][None, None], frames[i + 1][None, None])[0, 0]
+            mid = pair_fn(frames[i][None], frames[i + 1][None])[0]
             ok = ok and bool(torch.equal(res[2 * i + 1], mid)) and bool(torch.equal(res[2 * i], frames[i]))
     seen = world
     if dist is not None:  # ranks that actually answered on the RCCL communicator, and what each forwarded
