@@ -14,11 +14,20 @@ align_corners=True, i.e. with a scale that depends on the WHOLE image's size.  H
     (`fiunet_forward_strip`), so the kept rows are the un-tiled result - bit for bit wherever the
     kernels take the same path (the split-K of very small problems can differ; see the tests).
 
-Multi-GPU: one process per GPU, rank r computes band r.  The only traffic is the scatter of the
-input bands (+halo) from the rank that holds the frames and the gather of the output bands, as
-point-to-point send/recv (RCCL over the direct xGMI links on GPUs, gloo in the CPU tests); there is
-no collective and no exchange inside the forward.  There is NO neighbour-to-neighbour halo exchange
-(SURVEY 8e option A): the halo is input, cut from the root's copy of the frames.
+Multi-GPU: one process per GPU, rank r computes band r; point-to-point send/recv only (RCCL over the
+direct xGMI links on GPUs, gloo in the CPU tests), no collective and no exchange inside the forward.
+Two ways to get a band's input halo to its rank:
+
+  * `forward_tiled_distributed` - the rank that holds the frames sends every band WITH its halo (the
+    halo rows cross the root's links twice);
+  * `forward_tiled_halo_exchange` (round 5; BASELINE configs[4] "spatial-tile across 4 GPUs with xGMI
+    halo exchange") - the root scatters the CORE rows only, or the ranks already hold them (a row-sharded
+    decoder), and every rank fetches its 112 halo rows per cut edge from the ranks whose cores contain
+    them: its two NEIGHBOURS for bands of at least 112 rows, in one grouped send/recv - 2 x 112 x W
+    uint8 pixels per cut and frame over the neighbours' own links, in parallel on every cut.
+Either way the halo is INPUT (SURVEY 8e option B: the halo's outputs are recomputed and discarded);
+the per-layer activation-row exchange of SURVEY 8e option A (~22 latency-bound messages per forward)
+is not built.  Neither path has run over RCCL on more than one GPU (no multi-GPU box in this build).
 
 Wire format: the dtype of the frames.  Video frames are uint8 (`wire=torch.uint8`, SURVEY 8e "keep frames
 uint8 on the wire"): bands travel as uint8 - a quarter of the fp32 bytes in both directions - and every
@@ -101,6 +110,104 @@ def forward_tiled(strip_fn: StripFn, frame1: torch.Tensor, frame2: torch.Tensor,
 
 def _p2p(ops):
     transport.p2p(ops)
+
+
+def exchange_halos(core1: torch.Tensor, core2: torch.Tensor, plan: List[Strip], rank: int, width: int, device,
+                   group=None):
+    """Neighbour halo exchange: every rank holds the CORE rows [core0, core1) of both frames (`[B, C, rows, W]`)
+    and needs [ext0, ext1).  Rank q sends rank r the rows of q's core that fall inside r's halo; for bands of at
+    least `halo` rows those are r's two neighbours only.  One grouped batch of sends and receives per rank, peers
+    in rank order on every rank (a consistent issue order, as in video.py).  Returns the two bands
+    `[B, C, ext1 - ext0, W]` (the core is copied in place between the received halos)."""
+    mine = plan[rank]
+    b, c = core1.shape[0], core1.shape[1]
+    band1 = torch.empty((b, c, mine.ext1 - mine.ext0, width), dtype=core1.dtype, device=device)
+    band2 = torch.empty_like(band1)
+    band1[..., mine.core0 - mine.ext0:mine.core1 - mine.ext0, :] = core1
+    band2[..., mine.core0 - mine.ext0:mine.core1 - mine.ext0, :] = core2
+    ops, landing = [], []
+    for q, other in enumerate(plan):
+        if q == rank or other.core1 <= other.core0 or mine.core1 <= mine.core0:
+            continue
+        # what q needs from my core
+        s0, s1 = max(other.ext0, mine.core0), min(other.ext1, mine.core1)
+        if s1 > s0:
+            for core in (core1, core2):
+                ops.append(dist.P2POp(dist.isend, core[..., s0 - mine.core0:s1 - mine.core0, :].contiguous(), q, group))
+        # what I need from q's core
+        r0, r1 = max(mine.ext0, other.core0), min(mine.ext1, other.core1)
+        if r1 > r0:
+            for band in (band1, band2):
+                buf = torch.empty((b, c, r1 - r0, width), dtype=core1.dtype, device=device)
+                ops.append(dist.P2POp(dist.irecv, buf, q, group))
+                landing.append((band, r0 - mine.ext0, r1 - mine.ext0, buf))
+    _p2p(ops)
+    for band, a0, a1, buf in landing:
+        band[..., a0:a1, :] = buf
+    return band1, band2
+
+
+def forward_tiled_halo_exchange(strip_fn: StripFn, frame1: Optional[torch.Tensor], frame2: Optional[torch.Tensor],
+                                shape, device, root: int = 0, halo: int = HALO, group=None,
+                                wire: torch.dtype = torch.float32, pre=None, post=None,
+                                cores=None) -> Optional[torch.Tensor]:
+    """Spatial tiling with a neighbour-to-neighbour halo exchange.  Rank `root` holds the pair `[B, C, H, W]`
+    (dtype `wire`) and scatters the CORE rows of every band - or, `cores=(core1, core2)`, every rank already
+    holds its own core rows and `frame1` / `frame2` are ignored; the ranks exchange their halos among themselves
+    (`exchange_halos`), compute their bands, and `root` gathers and returns the assembled output (the others None).
+    Same result as `forward_tiled_distributed`, bit for bit."""
+    rank, world = dist.get_rank(group), dist.get_world_size(group)
+    if wire not in (torch.float32, torch.uint8):
+        raise ValueError("wire must be torch.float32 or torch.uint8")
+    if wire == torch.uint8:
+        strip_fn = u8_strip_fn(strip_fn, pre, post)
+    b, c, h, w = shape
+    plan = strip_plan(h, world, halo)
+    mine = plan[rank]
+    have = mine.core1 > mine.core0
+    # 1. core rows: root -> ranks (no halo on these links)
+    if cores is not None:
+        c1, c2 = cores
+    elif rank == root:
+        ops = []
+        for r, s in enumerate(plan):
+            if r != root and s.core1 > s.core0:
+                ops.append(dist.P2POp(dist.isend, frame1[..., s.core0:s.core1, :].contiguous(), r, group))
+                ops.append(dist.P2POp(dist.isend, frame2[..., s.core0:s.core1, :].contiguous(), r, group))
+        _p2p(ops)
+        c1 = frame1[..., mine.core0:mine.core1, :].contiguous()
+        c2 = frame2[..., mine.core0:mine.core1, :].contiguous()
+    else:
+        c1 = torch.empty((b, c, max(mine.core1 - mine.core0, 0), w), dtype=wire, device=device)
+        c2 = torch.empty_like(c1)
+        if have:
+            _p2p([dist.P2POp(dist.irecv, c1, root, group), dist.P2POp(dist.irecv, c2, root, group)])
+    # 2. halos: rank <-> neighbours
+    core = None
+    if have:
+        f1, f2 = exchange_halos(c1, c2, plan, rank, w, device, group)
+        band = strip_fn(f1, f2, mine.ext0, h)
+        core = band[..., mine.core0 - mine.ext0:mine.core1 - mine.ext0, :].contiguous()
+    # 3. output cores: ranks -> root
+    if rank != root:
+        if core is not None:
+            _p2p([dist.P2POp(dist.isend, core, root, group)])
+        return None
+    out = torch.empty((b, c, h, w), dtype=wire, device=device)
+    ops, bufs = [], []
+    for r, s in enumerate(plan):
+        if s.core1 <= s.core0:
+            continue
+        if r == root:
+            out[..., s.core0:s.core1, :] = core
+        else:
+            buf = torch.empty((b, c, s.core1 - s.core0, w), dtype=wire, device=device)
+            bufs.append((s, buf))
+            ops.append(dist.P2POp(dist.irecv, buf, r, group))
+    _p2p(ops)
+    for s, buf in bufs:
+        out[..., s.core0:s.core1, :] = buf
+    return out
 
 
 def forward_tiled_distributed(strip_fn: StripFn, frame1: Optional[torch.Tensor],

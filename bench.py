@@ -434,7 +434,8 @@ def tile4k_single_gpu_leg(model, dev, reps=10):
 
 
 def tile4k_leg(model, dev, dist, rank, world, reps):
-    """BASELINE configs[4]: one 2160x3840 pair, `world` row bands + 112-row halo; uint8 frames, uint8 on the wire."""
+    """BASELINE configs[4]: one 2160x3840 pair, `world` row bands, 112-row halos exchanged between neighbours;
+    uint8 frames, uint8 on the wire."""
     from ai_based_frame_interpolation_amd import tiling as T
 
     torch.cuda.set_device(dev)
@@ -446,8 +447,8 @@ def tile4k_leg(model, dev, dist, rank, world, reps):
         f1 = torch.randint(0, 256, shape, device=dev, generator=gen, dtype=torch.uint8)
         f2 = torch.randint(0, 256, shape, device=dev, generator=gen, dtype=torch.uint8)
 
-    def once():
-        return T.forward_tiled_distributed(model.forward_strip, f1, f2, shape, dev, root=0, wire=torch.uint8)
+    def once():   # cores scattered from the root, 112-row halos fetched from the neighbours (uint8 everywhere)
+        return T.forward_tiled_halo_exchange(model.forward_strip, f1, f2, shape, dev, root=0, wire=torch.uint8)
 
     for _ in range(2):
         out = once()
@@ -458,7 +459,8 @@ def tile4k_leg(model, dev, dist, rank, world, reps):
     dist.barrier(); torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / reps
     res = {"ms_per_pair": round(dt * 1e3, 3), "pairs_per_s": round(1.0 / dt, 2), "strips": world,
-           "halo_rows": T.HALO, "precision": model.precision, "wire": "uint8 bands (input halo from the root), uint8 result"}
+           "halo_rows": T.HALO, "precision": model.precision, "wire": "uint8: core rows scattered from the root, 112-row input halos exchanged between neighbouring ranks, "
+                                                                       "uint8 result gathered (tiling.forward_tiled_halo_exchange)"}
     if rank == 0:
         whole = model.forward_u8(f1, f2)
         torch.cuda.synchronize()

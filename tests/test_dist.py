@@ -164,22 +164,40 @@ def _tile_worker(rank, world, port, h, q):
                                                 shape, torch.device("cpu"), wire=torch.uint8, pre=_cpu_pre, post=_cpu_post)
         tiling._p2p = orig
         assert all(d == torch.uint8 for d in sent) and (sent or h == 16), sent     # only bytes travel (h = 16: one band, no traffic)
+        # neighbour halo exchange (BASELINE configs[4]): the root sends CORE rows only, halos come from the neighbours
+        peers = []
+        tiling._p2p = lambda ops: (peers.extend((("s" if o.op is dist.isend else "r"), o.group_peer if hasattr(o, "group_peer") else o.peer,
+                                                 tuple(o.tensor.shape)) for o in ops), orig(ops))[1]
+        outx = tiling.forward_tiled_halo_exchange(_box_strip_fn, f1 if rank == 0 else None, f2 if rank == 0 else None,
+                                                  shape, torch.device("cpu"))
+        outx8 = tiling.forward_tiled_halo_exchange(_box_strip_fn, u1 if rank == 0 else None, u2 if rank == 0 else None,
+                                                   shape, torch.device("cpu"), wire=torch.uint8, pre=_cpu_pre, post=_cpu_post)
+        tiling._p2p = orig
+        plan = tiling.strip_plan(h, world)
+        if plan[rank].core1 > plan[rank].core0 and rank != 0:
+            # a non-root rank receives core rows only from the root (never a halo), and talks to ranks whose cores hold its halo
+            core_rows = plan[rank].core1 - plan[rank].core0
+            from_root = [sh for d, p, sh in peers if d == "r" and p == 0]
+            assert (1, 1, core_rows, 20) in from_root, (from_root, core_rows)
+            assert all(sh[2] <= core_rows for sh in from_root)
         if rank == 0:
             want8 = _cpu_post(_box_strip_fn(_cpu_pre(u1), _cpu_pre(u2), 0, h))
             q.put(bool(torch.equal(out, _box_strip_fn(f1, f2, 0, h))) and out8.dtype == torch.uint8
-                  and bool(torch.equal(out8, want8)))
+                  and bool(torch.equal(out8, want8)) and bool(torch.equal(outx, out)) and bool(torch.equal(outx8, out8)))
         else:
-            assert out is None and out8 is None
+            assert out is None and out8 is None and outx is None and outx8 is None
     finally:
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("h", [16, 544, 1080])
-def test_tiled_forward_world2(h):
+@pytest.mark.parametrize("h,world", [(16, 2), (544, 2), (1080, 2), (1080, 3), (400, 3)])
+def test_tiled_forward_world2(h, world):
+    """Root-sent halo, uint8 wire, and the neighbour halo exchange (world 3: the middle band has two neighbours;
+    400 rows over 3 ranks: bands of 144 / 144 / 112 rows, the halo of the first reaches the core of the last)."""
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_tile_worker, args=(r, 2, port, h, q)) for r in range(2)]
+    procs = [ctx.Process(target=_tile_worker, args=(r, world, port, h, q)) for r in range(world)]
     for p in procs:
         p.start()
     for p in procs:

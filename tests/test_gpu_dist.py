@@ -99,18 +99,20 @@ def _tile_worker(rank, world, port, prec, h, w, q):
             u1 = torch.randint(0, 256, shape, device=dev, generator=g, dtype=torch.uint8)
             u2 = torch.randint(0, 256, shape, device=dev, generator=g, dtype=torch.uint8)
         out8 = tiling.forward_tiled_distributed(m.forward_strip, u1, u2, shape, dev, wire=torch.uint8)
+        # ... and with the halos fetched from the neighbour instead of the root (BASELINE configs[4])
+        outx8 = tiling.forward_tiled_halo_exchange(m.forward_strip, u1, u2, shape, dev, wire=torch.uint8)
         torch.cuda.synchronize()
         if rank == 0:
             whole = m(f1, f2)
             local = tiling.forward_tiled(m.forward_strip, f1, f2, world)   # same bands, no transport
             whole8 = m.forward_u8(u1, u2)
             torch.cuda.synchronize()
-            ok8 = out8.dtype == torch.uint8 and bool(torch.equal(out8, whole8))
+            ok8 = out8.dtype == torch.uint8 and bool(torch.equal(out8, whole8)) and bool(torch.equal(outx8, whole8))
             q.put(("tile", prec, bool(torch.equal(out, whole)) and ok8, 0,
                    f"2-rank vs un-tiled: {_diff_report(out, whole)} | single-process bands vs un-tiled: "
                    f"{_diff_report(local, whole)} | uint8 wire vs forward_u8 of the whole pair: {_diff_report(out8, whole8)}"))
         else:
-            assert out is None and out8 is None
+            assert out is None and out8 is None and outx8 is None
     finally:
         dist.destroy_process_group()
 
