@@ -10,7 +10,7 @@ TAG=${1:-default}
 O=$R/gpurun_out/prof_$TAG
 rm -rf "$O"; mkdir -p "$O"
 cd /tmp && export TMPDIR=/tmp
-B="python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --video-frames 0 --no-fp32 --no-power ${BENCH_ARGS:-}"
+B="python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --video-frames 0 --no-fp32 --no-power --no-tile4k ${BENCH_ARGS:-}"
 run() { name=$1; shift; timeout -k 10 300 rocprofv3 "$@" --output-format csv -d "$O/$name" -- $B > "$O/$name.log" 2>&1 && echo "pass $name ok"; }
 run trace --kernel-trace --stats &&
 run fetch --pmc FETCH_SIZE --kernel-trace &&
