@@ -429,8 +429,9 @@ def tile4k_single_gpu_leg(model, dev, reps=10):
             "recompute_factor": round(t_all / t_whole, 3), "tiled_equals_untiled_bitwise": equal,
             "slowest_band_ms": slow, "latency_bound_if_4_gpus_ms": slow, "precision": model.precision,
             "halo_rows": T.HALO,
-            "note": "ONE GPU: band times are what each of four GPUs would compute; no transfer is timed here "
-                    "(one-shot input halo from the root, no neighbour exchange: DESIGN section 7)"}
+            "note": "ONE GPU: band times are what each of four GPUs would compute; no transfer is timed here (N >= 2: "
+                    "tiling.forward_tiled_halo_exchange - cores from the root, 112-row input halos from the neighbours; "
+                    "DESIGN section 7)"}
 
 
 def tile4k_leg(model, dev, dist, rank, world, reps):
