@@ -1037,6 +1037,10 @@ int fiunet_min_unsplit_batch(const fiunet_ctx* ctx, int H, int W, int precision)
         g_err = "fiunet_min_unsplit_batch: bad arguments";
         return 0;
     }
+    if (!ctx->loaded) {   // the rule walks the loaded architecture's channel counts
+        g_err = "fiunet_min_unsplit_batch before fiunet_load_weights";
+        return 0;
+    }
     const int PL = precision == FIUNET_FP32 ? 16 : 32;
     int hs[5] = {H}, ws[5] = {W};
     for (int k = 1; k < 5; ++k) { hs[k] = hs[k - 1] / 2; ws[k] = ws[k - 1] / 2; }
