@@ -8,7 +8,8 @@
 //   * OutConv 1x1 + bias (:60)                    -> EPI_HEAD / EPI_HEAD3: reduced in the epilogue
 //   * the 2->64 stem conv (:72), bf16 gray path   -> SRC_STEM: evaluated inside the gather
 // so none of the pooled-input re-reads, upsampled, concatenated, stem-output or last-activation
-// tensors is ever materialised in HBM.
+// tensors is ever materialised in HBM.  The same kernel runs precision "bf16x2" (gather mode SRC_DIRECT_X2: two bf16
+// pieces per activation and weight, three MFMAs per product - the reference's fp32 tolerance on the bf16 pipe).
 //
 // Mapping onto the hardware (one workgroup = 4 waves = 256 threads, 2 workgroups per CU):
 //   * GEMM view: D[cout][pixel] += W[cout][k] * X[k][pixel], k = (channel plane, kx, ky).
@@ -77,7 +78,7 @@ struct ConvArgs {
     void* dst;           // [B][Cout/PL][H][W][PL] or nullptr (fused head only)
     void* pool_dst;      // EPI_POOL: [B][Cout/PL][H/2][W/2][PL], MaxPool2d(2) of dst
     int B, H, W;         // conv input == output spatial size
-    int C0, C1, Cout;
+    int C0, C1, Cout;    // (SRC_DIRECT_X2: REAL channel counts; every tensor then holds its hi planes followed by its lo planes)
     int lowH, lowW;      // CONCAT_UP: spatial size of src1
     int padT, padL;      // CONCAT_UP: F.pad top/left (unet.py:52-53)
     float sy, sx;        // CONCAT_UP: (low-1)/(2*low-1), align_corners=True scale
