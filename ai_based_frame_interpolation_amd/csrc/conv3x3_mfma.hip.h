@@ -56,7 +56,13 @@ enum SrcMode { SRC_DIRECT = 0, SRC_POOL = 1 /* host-side tag only */, SRC_CONCAT
                // (the dropped wl*xl term is 2^-16 relative).  The K loop runs three "virtual planes" per real plane of 32
                // channels - (xh, wh), (xh, wl), (xl, wh) - and the second one reuses the in-tile of the first: every piece
                // is stored once and gathered once.  Every epilogue of this mode writes the two pieces of its output.
-               SRC_DIRECT_X2 = 4 };
+               SRC_DIRECT_X2 = 4,
+               // bf16x2 + fused stem (gray): the stem conv is evaluated inside the gather as in SRC_STEM, once for the hi
+               // piece and once more for the lo piece of each of its two 32-channel planes (same split-bf16 MFMAs, ~2^-16
+               // relative: this precision's own accuracy class); the 64-channel two-piece stem output never goes to HBM
+               SRC_STEM_X2 = 5 };
+constexpr bool src_is_stem(int mode) { return mode == SRC_STEM || mode == SRC_STEM_X2; }
+constexpr bool src_is_x2(int mode) { return mode == SRC_DIRECT_X2 || mode == SRC_STEM_X2; }
 
 // Activation layout in HBM: plane-major blocked channels-last, [B][C/PL][H][W][PL] with one
 // 64-byte "plane" record per pixel (PL = 32 bf16 / 16 fp32 channels).  A tile row of one plane is
@@ -484,7 +490,7 @@ template <int BN, int TH, int TW, int MODE> struct ConvTile {
     // ds_read2_b32 (lanes 0-31, 32 banks) - sit 144 = 16 (mod 32) banks apart: no conflicts (separate hi
     // and lo images of pitch 36 put rows py, py+1 only 4 banks apart: 2-way conflicts on 12 of 16 lanes).
     static constexpr int PATCH_W = TW + 4, PATCH_H = TH + 4, PATCH_PITCH = 2 * PATCH_W;
-    static_assert(MODE != SRC_STEM || (2 * PATCH_PITCH) % 32 == 16, "patch pitch: lane groups 0/1 must not share banks");
+    static_assert(!src_is_stem(MODE) || (2 * PATCH_PITCH) % 32 == 16, "patch pitch: lane groups 0/1 must not share banks");
     static constexpr int PATCH_OFF = IN_BYTES + 2 * W_BYTES + SPARE_BYTES;
     // The operand of the bias k-slot - PATCH_W dwords {1.0, 0} followed by PATCH_W zero dwords (its lo
     // part), which all lanes of lane group 3 read at the same address (a broadcast) - lives in the
@@ -493,8 +499,8 @@ template <int BN, int TH, int TW, int MODE> struct ConvTile {
     // filling the CU's LDS exactly) this kernel ran 5 % slower.
     static constexpr int PATCH_TAIL_OFF = (TW + 2) * 64;                 // byte offset inside the in-tile
     static constexpr int PATCH_TAIL = 2 * PATCH_W * 4;
-    static_assert(MODE != SRC_STEM || PATCH_TAIL_OFF + PATCH_TAIL <= TWP * 64, "bias operand must fit the row-pitch filler");
-    static constexpr int PATCH_BYTES = MODE == SRC_STEM ? PATCH_H * PATCH_PITCH * 4 : 0;
+    static_assert(!src_is_stem(MODE) || PATCH_TAIL_OFF + PATCH_TAIL <= TWP * 64, "bias operand must fit the row-pitch filler");
+    static constexpr int PATCH_BYTES = src_is_stem(MODE) ? PATCH_H * PATCH_PITCH * 4 : 0;
     // CONCAT_UP: the bilinear mapping of this tile, one 16-B entry per in-tile row and per in-tile
     // pixel column (same for every plane, so it is evaluated once per tile, not per plane)
     static constexpr int TAB_OFF = PATCH_OFF + ((PATCH_BYTES + 15) / 16) * 16;
@@ -502,10 +508,10 @@ template <int BN, int TH, int TW, int MODE> struct ConvTile {
     // SRC_STEM: plane 1's stem weights (hi and lo halves of two 16-cout tiles), parked here by
     // LDS-DMA at kernel start so the plane boundary does not wait on a global load
     static constexpr int STEMW_OFF = TAB_OFF + TAB_BYTES;
-    static constexpr int STEMW_BYTES = MODE == SRC_STEM ? 4096 : 0;
+    static constexpr int STEMW_BYTES = src_is_stem(MODE) ? 4096 : 0;
     static constexpr int LDS_BYTES = STEMW_OFF + STEMW_BYTES;
     static_assert(LDS_BYTES <= 80 * 1024, "two workgroups must fit in the CU's 160 KiB of LDS");
-    static_assert(MODE != SRC_STEM || LDS_BYTES <= 63 * 1280, "fused-stem kernel: stay below 64 LDS granules");
+    static_assert(!src_is_stem(MODE) || LDS_BYTES <= 63 * 1280, "fused-stem kernel: stay below 64 LDS granules");
 };
 
 // 16-pixel fragments per wave: 8 (wave tile 64 couts x 128 pixels, 128 accumulator registers, two
@@ -862,13 +868,14 @@ __global__ __launch_bounds__(256, conv_occupancy(BN, TH, TW)) void conv3x3_mfma_
     static_assert(Tile::LDS_BYTES * conv_occupancy(BN, TH, TW) <= 160 * 1024, "LDS per CU");
     constexpr int HNC = EPI == EPI_HEAD ? 1 : (EPI == EPI_HEAD3 ? 3 : 0);  // fused-head classes
     static_assert(HNC == 0 || BN == 64, "fused head needs all 64 couts in one wave");
-    static_assert(MODE == SRC_DIRECT || MODE == SRC_CONCAT_UP || MODE == SRC_STEM || MODE == SRC_DIRECT_X2,
-                  "pooling is fused into the producer");
-    // precision "bf16x2" (SRC_DIRECT_X2): two-piece activations and weights, three virtual planes per real plane
-    constexpr bool X2 = MODE == SRC_DIRECT_X2;
-    constexpr bool DIRECT = MODE == SRC_DIRECT || X2;
+    static_assert(MODE == SRC_DIRECT || MODE == SRC_CONCAT_UP || MODE == SRC_STEM || MODE == SRC_DIRECT_X2 ||
+                  MODE == SRC_STEM_X2, "pooling is fused into the producer");
+    // precision "bf16x2" (SRC_DIRECT_X2 / SRC_STEM_X2): two-piece activations and weights, three virtual planes per real plane
+    constexpr bool X2 = src_is_x2(MODE);
+    constexpr bool STEM = src_is_stem(MODE);
+    constexpr bool DIRECT = MODE == SRC_DIRECT || MODE == SRC_DIRECT_X2;
     static_assert(!X2 || sizeof(T) == 2, "two-piece operands are bf16");
-    static_assert(MODE != SRC_STEM || (sizeof(T) == 2 && BN == 64), "fused stem: bf16, 64 couts");
+    static_assert(!STEM || (sizeof(T) == 2 && BN == 64), "fused stem: bf16, 64 couts");
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* const lds_in = smem;
@@ -983,7 +990,7 @@ __global__ __launch_bounds__(256, conv_occupancy(BN, TH, TW)) void conv3x3_mfma_
     static_assert(NPW <= 32, "one mask bit per piece of a wave");
     constexpr int PM_DY = 64 / TWP, PM_DX = 64 % TWP;
     const unsigned pm_dlin = (unsigned)(PM_DY * aW + PM_DX) * 64u, pm_dwrap = (unsigned)(aW - TWP) * 64u;
-    if constexpr (MODE != SRC_STEM) {
+    if constexpr (!STEM) {
         // one division per tile; every further piece is the previous one + 64 in-tile pixels (the hoisted
         // kernels keep the resulting offsets, the others the first offset and two bit masks)
         const int row0 = wave * 16 + (lane >> 2);
@@ -1025,7 +1032,7 @@ __global__ __launch_bounds__(256, conv_occupancy(BN, TH, TW)) void conv3x3_mfma_
     // Padding slots of the in-tile (pixels outside the image, row-pitch filler) are the same for every
     // plane of the tile: they are zeroed ONCE here, and the per-plane DMAs simply leave those lanes
     // switched off (the interpolated planes of a concat conv write zeros there themselves).
-    if constexpr (MODE != SRC_STEM) {
+    if constexpr (!STEM) {
         for_pieces([&](int j, bool ok, unsigned) __attribute__((always_inline)) {
             if (!ok) *reinterpret_cast<uint4*>(lds_in + j * 1024 + lane * 16) = make_uint4(0u, 0u, 0u, 0u);
         });
@@ -1225,7 +1232,7 @@ __global__ __launch_bounds__(256, conv_occupancy(BN, TH, TW)) void conv3x3_mfma_
     char* const patch = smem + Tile::PATCH_OFF;
     constexpr int PW = Tile::PATCH_W, PH = Tile::PATCH_H, PP = Tile::PATCH_PITCH;
     auto stage_patch = [&]() __attribute__((always_inline)) {
-        if constexpr (MODE == SRC_STEM) {
+        if constexpr (STEM) {
             // one thread = one patch pixel (both frames): one address, one dither value, one dword store
             // for the hi pair and one for the lo pair (the prologue is VALU-bound: SQ_INSTS_VALU per wave
             // tracks its time, profiles/r03_pmc_ab_stem.txt)
@@ -1288,8 +1295,16 @@ __global__ __launch_bounds__(256, conv_occupancy(BN, TH, TW)) void conv3x3_mfma_
     // are parked in LDS by DMA at kernel start and picked up at the plane boundary.
     struct StemW { uint4 wh[2], wl[2]; };
     StemW stem_w0;
+    auto stem_park = [&](int plane) __attribute__((always_inline)) {   // LDS-DMA of one plane's stem weights into STEMW
+        if constexpr (STEM && X2)   // issued again inside the K loop: scalar base + 32-bit lane offset, so that no 64-bit
+            glds16s((const char*)a.stem_w + (wave >> 1) * 4096 + (2 * plane + (wave & 1)) * 1024, (unsigned)lane * 16u,   // per-lane pointer lives across it
+                    __builtin_amdgcn_readfirstlane(lds_in_addr + (unsigned)(Tile::STEMW_OFF + wave * 1024)));
+        else if constexpr (STEM)
+            glds16((const char*)a.stem_w + (wave >> 1) * 4096 + (2 * plane + (wave & 1)) * 1024 + lane * 16,
+                   __builtin_amdgcn_readfirstlane(lds_in_addr + (unsigned)(Tile::STEMW_OFF + wave * 1024)));
+    };
     auto stem_load = [&](StemW& w) __attribute__((always_inline)) {
-        if constexpr (MODE == SRC_STEM) {
+        if constexpr (STEM) {
             int lane_ofs = l15 * 64 + lc * 16;     // opaque: keeps hipcc from forming the 64-bit
             asm volatile("" : "+v"(lane_ofs));     // per-lane pointer before the K loop and spilling it
 #pragma unroll
@@ -1297,13 +1312,13 @@ __global__ __launch_bounds__(256, conv_occupancy(BN, TH, TW)) void conv3x3_mfma_
                 w.wh[h] = ldg16((const char*)a.stem_w + h * 1024 + lane_ofs);
                 w.wl[h] = ldg16((const char*)a.stem_w + 4096 + h * 1024 + lane_ofs);
             }
-            // plane 1: wave w moves [hi h0 | hi h1 | lo h0 | lo h1][w], lane-linear
-            glds16((const char*)a.stem_w + (wave >> 1) * 4096 + (2 + (wave & 1)) * 1024 + lane * 16,
-                   __builtin_amdgcn_readfirstlane(lds_in_addr + (unsigned)(Tile::STEMW_OFF + wave * 1024)));
+            // plane 1 (X2: plane 0 again - its lo piece is evaluated from the same weights; plane 1's follow by
+            // stem_park(1) once every wave has picked these up): wave w moves [hi h0 | hi h1 | lo h0 | lo h1][w], lane-linear
+            stem_park(X2 ? 0 : 1);
         }
     };
     auto stem_parked = [&](StemW& w) __attribute__((always_inline)) {
-        if constexpr (MODE == SRC_STEM) {
+        if constexpr (STEM) {
             const char* const base = smem + Tile::STEMW_OFF + l15 * 64 + lc * 16;
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
@@ -1312,8 +1327,8 @@ __global__ __launch_bounds__(256, conv_occupancy(BN, TH, TW)) void conv3x3_mfma_
             }
         }
     };
-    auto gather_plane_stem = [&](const StemW& w) __attribute__((always_inline)) {
-        if constexpr (MODE == SRC_STEM) {
+    auto gather_plane_stem = [&](const StemW& w, bool lo_piece = false) __attribute__((always_inline)) {
+        if constexpr (STEM) {
             // lane groups 0, 1, 2 read patch rows py, py+2, py+1 (so that the two groups served together
             // by a ds_read2_b32, lanes 0-31, sit 2 * pitch = 16 banks apart); lane group 3 (k = 24..31, only
             // k = 24 has a weight: the BatchNorm shift) reads the {1.0, 0} dwords / their zero lo part at one
@@ -1361,10 +1376,20 @@ __global__ __launch_bounds__(256, conv_occupancy(BN, TH, TW)) void conv3x3_mfma_
                 // bf16_row_to_cout): the lane's 8 values are ONE 16-B chunk of the pixel's record - one
                 // ds_write_b128 (2-way bank conflicts) instead of two ds_write_b64 (4-way)
                 const int row = f.dst;
-                const uint4 pk = make_uint4(relu_pk_bf16(pack_bf16x2_pk(s4[0][0], s4[0][1])),
-                                            relu_pk_bf16(pack_bf16x2_pk(s4[0][2], s4[0][3])),
-                                            relu_pk_bf16(pack_bf16x2_pk(s4[1][0], s4[1][1])),
-                                            relu_pk_bf16(pack_bf16x2_pk(s4[1][2], s4[1][3])));
+                uint4 pk = make_uint4(relu_pk_bf16(pack_bf16x2_pk(s4[0][0], s4[0][1])),
+                                      relu_pk_bf16(pack_bf16x2_pk(s4[0][2], s4[0][3])),
+                                      relu_pk_bf16(pack_bf16x2_pk(s4[1][0], s4[1][1])),
+                                      relu_pk_bf16(pack_bf16x2_pk(s4[1][2], s4[1][3])));
+                if constexpr (X2) {
+                    if (lo_piece) {   // (wave-uniform) lo = RNE bf16 of relu(v) - hi; a negative v has hi = lo = +0
+                        auto lo2 = [](float v0, float v1, unsigned hi) __attribute__((always_inline)) {
+                            return pack_bf16x2_pk(fmaxf(v0, 0.f) - __uint_as_float(hi << 16),
+                                                  fmaxf(v1, 0.f) - __uint_as_float(hi & 0xffff0000u));
+                        };
+                        pk = make_uint4(lo2(s4[0][0], s4[0][1], pk.x), lo2(s4[0][2], s4[0][3], pk.y),
+                                        lo2(s4[1][0], s4[1][1], pk.z), lo2(s4[1][2], s4[1][3], pk.w));
+                    }
+                }
                 // address = row * 64 + ((lc ^ swz(row)) << 4), with the swizzle as one xor of bit 5
                 if (row < THP * TWP) *reinterpret_cast<uint4*>(lds_in + ((row * 64 + lc * 16) ^ ((row & 4) << 3))) = pk;
             };
@@ -1398,7 +1423,15 @@ __global__ __launch_bounds__(256, conv_occupancy(BN, TH, TW)) void conv3x3_mfma_
 #ifdef FIUNET_DIAG_NO_GATHER  // timing diagnostic: compute side alone (stale LDS, results are garbage)
         return;
 #endif
-        if constexpr (MODE == SRC_STEM) {  // exactly two planes (64 stem channels)
+        if constexpr (STEM && X2) {   // virtual planes 0 / 2 / 3 / 5 = (plane 0 hi, plane 0 lo, plane 1 hi, plane 1 lo)
+            if (first) {
+                gather_plane_stem(stem_w0, false);
+            } else {
+                StemW w;
+                stem_parked(w);   // plane 0's weights at virtual plane 2, plane 1's at 3 and 5 (see the K loop)
+                gather_plane_stem(w, plane == 2 || plane == 5);
+            }
+        } else if constexpr (STEM) {  // exactly two planes (64 stem channels)
             if (first) {
                 gather_plane_stem(stem_w0);
             } else {
@@ -1414,7 +1447,7 @@ __global__ __launch_bounds__(256, conv_occupancy(BN, TH, TW)) void conv3x3_mfma_
     // diagnostic build (-DFIUNET_STAMP): where does a wave's time go?  [0] total [1] prologue
     // [2] MFMA phases [3] end-of-step wait+barrier [4] plane-boundary gather (rest) [5] epilogue
     // [6] upsample staging DMA + wait [7] upsample interpolation   (s_memtime ticks)
-    if constexpr (MODE == SRC_STEM) {
+    if constexpr (STEM) {
         stem_load(stem_w0);
         stage_patch();
         __syncthreads();
@@ -1522,6 +1555,9 @@ __global__ __launch_bounds__(256, conv_occupancy(BN, TH, TW)) void conv3x3_mfma_
                 gather_plane(plane + 1, step & 1, false);
                 lds_dma_wait_all();
                 __syncthreads();
+                // fused x2 stem: every wave has read plane 0's parked weights for the last time (lo piece): plane 1's
+                // take their place, landing under the next three steps (each step end waits for this wave's DMAs)
+                if constexpr (STEM && X2) { if (plane + 1 == 2) stem_park(1); }
                 STAMP(4);
             } else {
                 lds_dma_wait_all();   // this wave's pieces of W(step+1) landed

@@ -363,8 +363,8 @@ inline unsigned grid_for(size_t n);
 template <typename T, int BN, int TH, int TW, int MODE, int EPI>
 int launch_conv_maybe_split(ConvArgs a, hipStream_t s)
 {
-    constexpr bool X2 = MODE == SRC_DIRECT_X2;   // precision bf16x2: two-piece operands and output, 3 virtual planes per plane
-    if constexpr (MODE != SRC_STEM && (EPI == EPI_PLAIN || EPI == EPI_POOL)) {
+    constexpr bool X2 = src_is_x2(MODE);   // precision bf16x2: two-piece operands and output, 3 virtual planes per plane
+    if constexpr (!src_is_stem(MODE) && (EPI == EPI_PLAIN || EPI == EPI_POOL)) {
         const long long nblk = (long long)a.B * ((a.W + TW - 1) / TW) * ((a.H + TH - 1) / TH) * (a.Cout / BN);
         const int nplanes = (a.C0 + a.C1) / Elem<T>::PL * (X2 ? 3 : 1);
         const int ksplit = ksplit_rule(nblk, nplanes, a.B, a.H, a.W, a.Cout);
@@ -429,7 +429,11 @@ PlanOpts plan_opts(const fiunet_ctx* ctx, int H, int W, int precision)
     o.cout = ctx->cout;
     o.convt = !ctx->bilinear;
     o.x2 = precision == FIUNET_BF16X2;
-    if (o.x2) { o.fused_stem = false; o.fused_head = !o.keep_all; o.unfused = o.gather_up = false; }
+    if (o.x2) {   // gray: the stem is evaluated inside conv 1's gather (SRC_STEM_X2) unless the read-back wants its output
+        o.fused_stem = ctx->cf == 1 && !o.keep_all && ctx->stem_w_split != nullptr && prefer_wide(H, W, 16, 32, 32, 16);
+        o.fused_head = !o.keep_all;
+        o.unfused = o.gather_up = false;
+    }
     return o;
 }
 
@@ -464,10 +468,13 @@ template <typename T> int launch_conv(const ConvArgs& a, int mode, int epi, hipS
         if (mode == SRC_DIRECT_X2 && epi == EPI_POOL) return launch_conv_shape<T, SRC_DIRECT_X2, EPI_POOL>(a, s);
         if (mode == SRC_DIRECT_X2 && epi == EPI_HEAD) return launch_conv_shape<T, SRC_DIRECT_X2, EPI_HEAD>(a, s);
         if (mode == SRC_DIRECT_X2 && epi == EPI_HEAD3) return launch_conv_shape<T, SRC_DIRECT_X2, EPI_HEAD3>(a, s);
+
     }
     if constexpr (sizeof(T) == 2) {
         if (mode == SRC_STEM && epi == EPI_POOL && a.Cout == 64)  // 16x32 tiles only (LDS budget)
             return launch_conv_cfg<T, 64, 16, 32, SRC_STEM, EPI_POOL>(a, s);
+        if (mode == SRC_STEM_X2 && epi == EPI_POOL && a.Cout == 64)
+            return launch_conv_cfg<T, 64, 16, 32, SRC_STEM_X2, EPI_POOL>(a, s);
     }
     return fail(FIUNET_ERR_INVALID_ARG, "unsupported gather/epilogue combination");
 }
@@ -678,7 +685,8 @@ int forward_impl(fiunet_ctx* ctx, const float* f1, const float* f2, float* out, 
 // Small problems K-split like the other precisions (splitk_finalize_kernel writes the two pieces, x2_maxpool2_kernel
 // the pooled copy).  FIUNET_OPT_KEEP_ALL keeps every activation for the read-back; no ablation path.
 int forward_x2(fiunet_ctx* ctx, const float* f1, const float* f2, float* out, int B, int H, int W, char* ws,
-               const Plan& p, hipStream_t s, int y_origin, int Hg, uint8_t* out_u8)
+               const Plan& p, hipStream_t s, int y_origin, int Hg, uint8_t* out_u8, const uint8_t* u1 = nullptr,
+               const uint8_t* u2 = nullptr)
 {
     using T = __bf16;
     if (!ctx->x2_ready)
@@ -700,7 +708,14 @@ int forward_x2(fiunet_ctx* ctx, const float* f1, const float* f2, float* out, in
         ctx->ev_used += NCONV + 1;
         HIP_TRY(hipEventRecord(ev[0], s));
     }
-    {   // conv 0: exact-fp32 stem (no dither: this is the fp32-contract path), its epilogue splits into the two pieces
+    const bool fuse_stem = plan_opts(ctx, H, W, FIUNET_BF16X2).fused_stem;   // gray, wide tiles, no read-back
+    if (fuse_stem) {
+        if (ev) {
+            HIP_TRY(hipEventRecord(ev[1], s));
+            ctx->layer_name[0] = "(stem fused into next stage)";
+            ctx->layer_flops[0] = 0.0;
+        }
+    } else {   // conv 0: exact-fp32 stem (no dither: this is the fp32-contract path), its epilogue splits into the two pieces
         const ConvWeights& cw = ctx->conv[0];
         const long long nruns = (long long)B * H * (((W + 15) / 16 + 7) / 8);
         dim3 grid((unsigned)std::min<long long>((nruns + 3) / 4, 256 * 64));
@@ -773,6 +788,13 @@ int forward_x2(fiunet_ctx* ctx, const float* f1, const float* f2, float* out, in
             a.src1 = up;
         }
         if (a.C0 + a.C1 != cw.cin) return fail(FIUNET_ERR_INVALID_ARG, "internal: bf16x2 channel plan mismatch");
+        int mode = SRC_DIRECT_X2;
+        if (i == 1 && fuse_stem) {   // the stem's two-piece output exists only as this conv's LDS tiles
+            mode = SRC_STEM_X2;
+            a.f1 = f1; a.f2 = f2; a.u1 = u1; a.u2 = u2;
+            a.stem_w = ctx->stem_w_split;
+            a.dither = 0.f;
+        }
         int epi = EPI_PLAIN;
         if (kPoolOut[i] >= 0) {
             epi = EPI_POOL;
@@ -784,11 +806,12 @@ int forward_x2(fiunet_ctx* ctx, const float* f1, const float* f2, float* out, in
             if (!keep_all) a.dst = nullptr;
         }
         g_name_out = ev ? &ctx->layer_name[i] : nullptr;
-        const int rc = launch_conv<T>(a, SRC_DIRECT_X2, epi, s);
+        const int rc = launch_conv<T>(a, mode, epi, s);
         g_name_out = nullptr;
         if (rc != FIUNET_OK) return rc;
         if (ev) {
             ctx->layer_flops[i] = 2.0 * B * a.H * a.W * 9.0 * cw.cin * cw.cout;   // algorithmic (the kernel executes 3x)
+            if (i == 1 && fuse_stem) ctx->layer_flops[i] += 2.0 * B * H * W * 9.0 * ctx->conv[0].cin * ctx->conv[0].cout;
             HIP_TRY(hipEventRecord(ev[i + 1], s));
         }
     }
@@ -1167,7 +1190,7 @@ int fiunet_forward_u8(fiunet_ctx* ctx, const uint8_t* frame1, const uint8_t* fra
     const uint8_t* u2 = in_f32 ? nullptr : frame2;
     uint8_t* ou = out_f32 ? nullptr : out;
     if (precision == FIUNET_BF16X2)
-        rc = forward_x2(ctx, a, b, o, B, H, W, ws, p, s, 0, H, ou);
+        rc = forward_x2(ctx, a, b, o, B, H, W, ws, p, s, 0, H, ou, u1, u2);
     else if (precision == FIUNET_BF16)
         rc = forward_impl<__bf16>(ctx, a, b, o, B, H, W, ws, p, s, 0, H, u1, u2, ou);
     else
