@@ -15,7 +15,7 @@ for r in csv.DictReader(open(f)):
     d["t"] = (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) * 1e-6
     d[r["Counter_Name"]] = d.get(r["Counter_Name"], 0.0) + float(r["Counter_Value"])
 ids = sorted(disp)
-last = ids[-19:]
+last = ids[-21:]   # one forward: 17 convs (the stem is fused into the first) + 4 x2_upsample launches
 for i in last:
     d = disp[i]
     if "GRBM_GUI_ACTIVE" not in d: continue
