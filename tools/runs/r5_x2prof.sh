@@ -1,8 +1,9 @@
+set -o pipefail
 cd $GRAFT_REPO_ROOT && mkdir -p gpurun_out/r5
 R=$PWD; O=$R/gpurun_out/r5/prof_x2; rm -rf $O; mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
-timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace -- python3 $R/tools/stage_times.py 4 1080 1920 bf16x2 1 5 > $O/trace.log 2>&1; echo "trace rc $?"
-timeout -k 10 300 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $O/sq -- python3 $R/tools/stage_times.py 4 1080 1920 bf16x2 1 3 > $O/sq.log 2>&1; echo "pmc rc $?"
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace -- python3 $R/tools/stage_times.py 4 1080 1920 bf16x2 1 5 > $O/trace.log 2>&1 || exit 1; echo "trace rc $?"
+timeout -k 10 300 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $O/sq -- python3 $R/tools/stage_times.py 4 1080 1920 bf16x2 1 3 > $O/sq.log 2>&1 || exit 1; echo "pmc rc $?"
 find $O -name "*kernel_stats.csv" -exec cp {} $R/gpurun_out/r5/x2_kernel_stats.csv \;
 python3 - $O/sq > $R/gpurun_out/r5/x2_pmc.txt <<'PY'
 import csv, glob, os, sys
