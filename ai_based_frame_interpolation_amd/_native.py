@@ -114,10 +114,21 @@ def lib() -> ctypes.CDLL:
     return L
 
 
+ERR_UNSUPPORTED = 7   # include/fiunet.h: enum fiunet_status
+
+
+class NativeError(RuntimeError):
+    """A non-OK status from the C ABI; `.status` is the fiunet_status code (the message carries the library's text)."""
+
+    def __init__(self, what: str, status: int, text: str):
+        super().__init__(f"{what} failed (status {status}): {text}")
+        self.status = status
+
+
 def check(rc: int, what: str) -> None:
     if rc != 0:
         msg = lib().fiunet_last_error_string()
-        raise RuntimeError(f"{what} failed (status {rc}): {msg.decode() if msg else '?'}")
+        raise NativeError(what, rc, msg.decode() if msg else "?")
 
 
 class Context:

@@ -361,8 +361,8 @@ class FrameInterpolationUNet(nn.Module):
             for k in (range(4) if with_up else ()):
                 try:
                     acts[UP_TAP_NAMES[k]] = self._ctx.read_activation(self._ws, b, h, w, prec, 18 + k)
-                except RuntimeError as e:
-                    if "status 7" not in str(e):   # FIUNET_ERR_UNSUPPORTED: not stored in this configuration
+                except _native.NativeError as e:
+                    if e.status != _native.ERR_UNSUPPORTED:   # (unsupported = not stored in this configuration)
                         raise
         finally:
             self._options = saved
