@@ -171,3 +171,25 @@ def test_bench_gpus_2_self_launches_on_one_card():
     assert d["rccl_ranks_seen"] == 2 and d["pairs_per_rank"] == [4, 4], d
     assert d["video_sharded"]["spot_check_equal_to_single_gpu"] is True
     assert "REHEARSAL" in d["collective_backend"]
+
+
+def test_bench_under_torch_distributed_run_one_rccl_rank():
+    """The form the driver uses for N > 1 (`python -m torch.distributed.run ... bench.py --gpus N`), with the one rank a
+    one-GPU box has: RCCL communicator creation, the sharded video leg over the nccl backend, one JSON line, rc 0."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT",
+                                                            "FIUNET_BENCH_REHEARSE")}
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1",
+                        "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.join(root, "bench.py"),
+                        "--gpus", "1", "--steps", "2", "--warmup", "1", "--batch", "2", "--height", "360", "--width", "640",
+                        "--no-cpu-baseline", "--no-power", "--no-fp32", "--video-frames", "9"],
+                       env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.strip().startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 1 and d["value"] > 0
+    assert "rccl" in d["video_sharded"]["backend"] and d["video_sharded"]["spot_check_equal_to_single_gpu"] is True
