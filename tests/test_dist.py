@@ -174,6 +174,12 @@ def _tile_worker(rank, world, port, h, q):
                                                    shape, torch.device("cpu"), wire=torch.uint8, pre=_cpu_pre, post=_cpu_post)
         tiling._p2p = orig
         plan = tiling.strip_plan(h, world)
+        # ... and with the frames ALREADY row-sharded (every rank holds its own core rows; nothing is scattered)
+        mine = plan[rank]
+        outc = tiling.forward_tiled_halo_exchange(_box_strip_fn, None, None, shape, torch.device("cpu"),
+                                                  cores=(f1[..., mine.core0:mine.core1, :].contiguous(),
+                                                         f2[..., mine.core0:mine.core1, :].contiguous()))
+        assert (outc is None) == (rank != 0) and (rank != 0 or torch.equal(outc, outx))
         if plan[rank].core1 > plan[rank].core0 and rank != 0:
             # a non-root rank receives core rows only from the root (never a halo), and talks to ranks whose cores hold its halo
             core_rows = plan[rank].core1 - plan[rank].core0
