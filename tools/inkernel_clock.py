@@ -3,7 +3,8 @@ build stamps s_memtime (shader cycles) and s_memrealtime (constant 100 MHz) ONCE
 stage per forward; clock = d(memtime) / d(memrealtime) x 100 MHz, median over the waves, after >= 2 s of back-to-back
 forwards on random data.  Also the wall time of the stage in the same forward (HIP events), so that
     executed bf16 MFMA rate = 3^x2 x algorithmic FLOPs / time   and   MFMA-busy = that / (1024 FLOP/cycle/SIMD x 1024 SIMDs x clock)
-    FIUNET_LIB=ablibs/lib_clock.so python tools/inkernel_clock.py [B H W precision]"""
+    make -C ai_based_frame_interpolation_amd/csrc OUT=../../ablibs/lib_clock.so EXTRA=-DFIUNET_CLOCK
+    FIUNET_LIB=ablibs/lib_clock.so python tools/inkernel_clock.py [B H W precision [out.json]]"""
 import ctypes, os, statistics, sys, time
 import numpy as np, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT)

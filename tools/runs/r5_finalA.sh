@@ -1,5 +1,6 @@
 set -o pipefail
 cd $GRAFT_REPO_ROOT && mkdir -p gpurun_out/r5f
+[ -f ablibs/lib_clock.so ] || { mkdir -p ablibs && make -C ai_based_frame_interpolation_amd/csrc OUT=../../ablibs/lib_clock.so EXTRA=-DFIUNET_CLOCK > /dev/null; }   # diagnostic build (git-ignored): built on the box when absent
 O=gpurun_out/r5f
 timeout -k 10 1000 python -m pytest tests -q -m gpu > $O/gpu_tests.log 2>&1 || { tail -30 $O/gpu_tests.log; exit 1; }
 tail -3 $O/gpu_tests.log
