@@ -267,7 +267,7 @@ def cpu_legs(dev, precision):
     par = {"checkpoint": "oracle.make_interpolating_state_dict(): 0.5*(f1+f2) carried through the x1 skip "
                          "+ seeded random deep network (~0.04 rms)",
            "psnr_cpu_vs_truth_db": round(O.psnr_u8(truth_u8.numpy(), ref_u8), 4)}
-    for prec in ("fp32", "bf16"):
+    for prec in ("fp32", "bf16x2", "bf16"):   # (bf16x2: the fast path that meets the fp32 tolerance; stem fused at this size)
         m.precision = prec
         hip_u8 = m.forward_u8(a_u8[None, None].to(dev), c_u8[None, None].to(dev))[0, 0].cpu().numpy()
         par[f"psnr_hip_{prec}_vs_truth_db"] = round(O.psnr_u8(truth_u8.numpy(), hip_u8), 4)
@@ -275,6 +275,7 @@ def cpu_legs(dev, precision):
         out = m(fa.to(dev), fc.to(dev)).cpu()
         par[f"max_abs_{prec}_vs_cpu_ref"] = round(float((out - ref).abs().max()), 8)
     par["psnr_delta_db"] = round(abs(par[f"psnr_hip_{precision}_vs_truth_db"] - par["psnr_cpu_vs_truth_db"]), 4)
+    par["psnr_delta_db_bf16x2"] = round(abs(par["psnr_hip_bf16x2_vs_truth_db"] - par["psnr_cpu_vs_truth_db"]), 4)
     # ---- the same criterion over more scenes, sizes and checkpoint seeds (bounded: ~5 s of CPU) ----
     try:
         sweep_rows, worst = _psnr_sweep(O, m, sd_i, dev, precision)
