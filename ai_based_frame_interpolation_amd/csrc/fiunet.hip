@@ -537,7 +537,7 @@ int forward_impl(fiunet_ctx* ctx, const float* f1, const float* f2, float* out, 
                 // persistent workgroups, one tile after the other: exactly as many as are resident at once (153 registers
                 // -> 3 waves per SIMD -> 3 workgroups per CU); with 1024 the last 256 ran a second round on a third of the chip
                 dim3 g2((unsigned)std::min<long long>(ntiles, 256 * FIUNET_RGB_STEM_OCC));
-                hipLaunchKernelGGL(stem_rgb_split_kernel, g2, dim3(256), 0, s, f1, f2, (const float*)cw.w_f32, cw.scale,
+                hipLaunchKernelGGL(stem_rgb_split_kernel<false>, g2, dim3(256), 0, s, f1, f2, (const float*)cw.w_f32, cw.scale,
                                    cw.shift, (__bf16*)act(0), B, H, W, stem_dither_amp, u1, u2);
                 stem_split_rgb = true;
             }
@@ -722,13 +722,18 @@ int forward_x2(fiunet_ctx* ctx, const float* f1, const float* f2, float* out, in
         if (ctx->cf == 1)
             hipLaunchKernelGGL((conv3x3_first_kernel<__bf16, 1, true>), grid, dim3(256), 0, s, f1, f2, (const float*)cw.w_f32,
                                cw.scale, cw.shift, (__bf16*)act(0), B, H, W, 0.f);
-        else
-            hipLaunchKernelGGL((conv3x3_first_kernel<__bf16, 3, true>), grid, dim3(256), 0, s, f1, f2, (const float*)cw.w_f32,
-                               cw.scale, cw.shift, (__bf16*)act(0), B, H, W, 0.f);
+        else {   // RGB: the split-bf16 MFMA stem with a two-piece epilogue (the exact-fp32 MFMA stem needs 56 fp32 MFMAs per
+                 // 16 pixels: it was the longest stage of the RGB network); it reads the uint8 frames itself on the video path
+            const long long ntiles = (long long)B * ((H + 15) / 16) * ((W + 31) / 32);
+            dim3 g2((unsigned)std::min<long long>(ntiles, 256 * FIUNET_RGB_STEM_OCC));
+            hipLaunchKernelGGL(stem_rgb_split_kernel<true>, g2, dim3(256), 0, s, f1, f2, (const float*)cw.w_f32, cw.scale,
+                               cw.shift, (__bf16*)act(0), B, H, W, 0.f, u1, u2);
+        }
         HIP_TRY(hipGetLastError());
         if (ev) {
             HIP_TRY(hipEventRecord(ev[1], s));
-            ctx->layer_name[0] = "conv3x3_first_kernel<f32 arithmetic, two-piece output>";
+            ctx->layer_name[0] = ctx->cf == 1 ? "conv3x3_first_kernel<f32 arithmetic, two-piece output>"
+                                              : "stem_rgb_split_kernel<two-piece output>";
             ctx->layer_flops[0] = 2.0 * B * H * W * 9.0 * cw.cin * cw.cout;
         }
     }
@@ -1143,8 +1148,8 @@ int fiunet_forward_strip(fiunet_ctx* ctx, const float* frame1, const float* fram
 static void u8_buffers(const fiunet_ctx* ctx, int H, int W, int precision, bool* in_f32, bool* out_f32)
 {
     const PlanOpts po = plan_opts(ctx, H, W, precision);
-    // the bf16 RGB stem (stem_rgb_split_kernel) reads the uint8 frames itself too
-    *in_f32 = !(po.fused_stem || (precision == FIUNET_BF16 && ctx->cf == 3));
+    // the bf16 / bf16x2 RGB stem (stem_rgb_split_kernel) reads the uint8 frames itself too
+    *in_f32 = !(po.fused_stem || ((precision == FIUNET_BF16 || precision == FIUNET_BF16X2) && ctx->cf == 3));
     *out_f32 = !po.fused_head;
 }
 

@@ -179,6 +179,9 @@ __global__ __launch_bounds__(256) void conv3x3_first_kernel(
 #ifndef FIUNET_RGB_STEM_OCC
 #define FIUNET_RGB_STEM_OCC 2
 #endif
+// X2 (precision bf16x2): `dst` is the two-piece tensor [hi planes | lo planes] of 2 x 64 channels - relu(acc) split in fp32
+// (the split-bf16 MFMAs' ~2^-16 relative accuracy is that precision's own class; no dither: the caller passes 0)
+template <bool X2 = false>
 __global__ __launch_bounds__(256, FIUNET_RGB_STEM_OCC) void stem_rgb_split_kernel(
     const float* __restrict__ f1, const float* __restrict__ f2, const float* __restrict__ w,  // w: [9 taps][6][64] fp32
     const float* __restrict__ scale, const float* __restrict__ shift, __bf16* __restrict__ dst, int B, int H, int W,
@@ -323,8 +326,18 @@ __global__ __launch_bounds__(256, FIUNET_RGB_STEM_OCC) void stem_rgb_split_kerne
                 for (int ct = 0; ct < 4; ++ct)
 #pragma unroll
                     for (int j = 0; j < 4; ++j) o16[ct * 4 + j] = fmaxf(acc[ct][j], 0.f);
-                *reinterpret_cast<uint4*>(op) = chunk_pack<__bf16>(o16);
-                *reinterpret_cast<uint4*>(op + 16) = chunk_pack<__bf16>(o16 + 8);
+                if constexpr (X2) {
+                    const size_t blk = (size_t)2 * H * W * 64;   // bytes from a hi record to its lo record (2 planes per piece)
+                    char* o2 = (char*)dst + (size_t)b * 2 * blk + blk_off((lc * 16) / 32, y, x, H, W) + (size_t)((lc * 16) % 32) * 2;
+                    float c0[8], c1[8];
+#pragma unroll
+                    for (int c = 0; c < 8; ++c) { c0[c] = o16[c]; c1[c] = o16[8 + c]; }
+                    x2_split_store(o2, blk, c0);
+                    x2_split_store(o2 + 16, blk, c1);
+                } else {
+                    *reinterpret_cast<uint4*>(op) = chunk_pack<__bf16>(o16);
+                    *reinterpret_cast<uint4*>(op + 16) = chunk_pack<__bf16>(o16 + 8);
+                }
             }
         }
     }

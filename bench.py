@@ -845,6 +845,26 @@ def bf16x2_leg(dev, with_oracle=True):
                     "algorithmic_tflops": round(fps * conv_flops(h, w) / 1e12, 2),
                     "executed_mfma_frac_of_bf16_peak": round(3 * fps * conv_flops(h, w) / 1e12 / PEAK_TFLOPS["bf16"], 4)}
         del f1, f2
+    # the RGB 6 -> 3 network (the north star's wording) in this precision, batch 4 of 1080p pairs
+    try:
+        rgbm = make_bench_model("bf16x2", frame_channels=3).to(dev).eval()
+        gen = torch.Generator(device=dev).manual_seed(1)
+        f1 = torch.rand(4, 3, 1080, 1920, device=dev, generator=gen) * 2 - 1
+        f2 = torch.rand(4, 3, 1080, 1920, device=dev, generator=gen) * 2 - 1
+        rgbm(f1, f2)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        torch.cuda.synchronize()
+        e0.record()
+        for _ in range(5):
+            rgbm(f1, f2)
+        e1.record()
+        torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1) / 5
+        out["rgb_b4_1080p"] = {"value": round(4 / (ms * 1e-3), 2), "unit": "frames/s", "ms_per_step": round(ms, 4), "steps": 5,
+                               "warmup": 1, "workload": "batch=4 1920x1080 synthetic RGB frame pairs, UNet(6->3, bilinear)"}
+        del rgbm, f1, f2
+    except Exception as e:  # noqa: BLE001 -- an extra entry, never the reason to lose the leg
+        out["rgb_b4_1080p"] = {"error": f"{type(e).__name__}: {e}"}
     if not with_oracle:
         return out
     from oracle import unet_oracle as O   # checker only, outside every timed region

@@ -344,7 +344,9 @@ def test_random_shapes_fp32_and_bf16_vs_oracle(model, dev, seeded_sd):
 
 @pytest.mark.parametrize("prec,cf,h,w,unfused", [("bf16", 1, 64, 96, False), ("bf16", 1, 33, 47, False),
                                                  ("bf16", 1, 48, 80, True), ("fp32", 1, 64, 96, False),
-                                                 ("bf16", 3, 40, 56, False), ("fp32", 3, 33, 47, False)])
+                                                 ("bf16", 3, 40, 56, False), ("fp32", 3, 33, 47, False),
+                                                 ("bf16x2", 1, 64, 96, False), ("bf16x2", 1, 33, 47, False),
+                                                 ("bf16x2", 3, 40, 56, False)])
 def test_u8_read_and_write_fused_into_stem_and_head_bitwise(dev, prec, cf, h, w, unfused):
     """fiunet_forward_u8 == fiunet_preprocess_u8 -> fiunet_forward -> fiunet_postprocess_u8 bit for bit
     (inference.py:31-35, :54-61), whether the uint8 frames are read by the fused stem / written by the fused
@@ -363,11 +365,11 @@ def test_u8_read_and_write_fused_into_stem_and_head_bitwise(dev, prec, cf, h, w,
     want = _native.postprocess_u8(m(_native.preprocess_u8(a), _native.preprocess_u8(b)))
     assert got.dtype == torch.uint8 and torch.equal(got, want)
     ctx = m._ctx
-    pcode = _native.BF16 if prec == "bf16" else _native.FP32
+    pcode = {"bf16": _native.BF16, "bf16x2": _native.BF16X2, "fp32": _native.FP32}[prec]
     base, u8b = ctx.workspace_bytes(2, h, w, pcode), ctx.workspace_bytes(2, h, w, pcode, u8=True)
     frame = -(-2 * cf * h * w * 4 // 256) * 256
-    fused_stem = prec == "bf16" and cf == 1 and not unfused and w >= 32  # 16x32 tiles preferred
-    stem_reads_u8 = fused_stem or (prec == "bf16" and cf == 3)           # round 4: the split-bf16 RGB stem does too
+    fused_stem = prec in ("bf16", "bf16x2") and cf == 1 and not unfused and w >= 32  # 16x32 tiles preferred (round 5: bf16x2 too)
+    stem_reads_u8 = fused_stem or (prec in ("bf16", "bf16x2") and cf == 3)           # the split-bf16 RGB stem does too
     nbuf = (0 if stem_reads_u8 else 2) + (1 if unfused else 0)
     assert u8b - base == nbuf * frame, (u8b - base, nbuf, frame)
 
