@@ -1,10 +1,12 @@
-"""Stress: repeat forwards of several shapes, check bitwise determinism against the first result."""
+"""Stress: repeat forwards of several shapes, check bitwise determinism against the first result.
+usage: python tools/stress.py [iters=40] [precision=bf16]"""
 import os, sys, time, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT)
 import ai_based_frame_interpolation_amd as P
 dev = torch.device("cuda:0")
 torch.manual_seed(0)
-m = P.FrameInterpolationUNet(bilinear=True, precision="bf16")
+prec = sys.argv[2] if len(sys.argv) > 2 else "bf16"
+m = P.FrameInterpolationUNet(bilinear=True, precision=prec)
 with torch.no_grad():
     for n, p in m.named_parameters():
         if p.dim() == 4 and p.shape[-1] == 3: p.normal_(0, (2.0 / (p.shape[1] * 9)) ** 0.5)
@@ -26,4 +28,4 @@ for it in range(iters):
             print("MISMATCH", key, it, (out - refs[key]).abs().max().item()); sys.exit(1)
         n += 1
     if it % 10 == 0: print(f"iter {it} ok, {n} forwards, {time.time() - t0:.1f} s", flush=True)
-print("STRESS OK", n, "forwards")
+print("STRESS OK", prec, n, "forwards")
