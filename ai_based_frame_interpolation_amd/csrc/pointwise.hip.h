@@ -171,9 +171,9 @@ __global__ __launch_bounds__(256) void conv3x3_first_kernel(
 // (x = xh + xl, |xl| <= 2^-9 |x|), the weights (BatchNorm scale folded in, shift riding in a bias k-slot whose data
 // operand is 1.0) are split the same way and kept in registers, and a 16-pixel fragment is
 //     acc += wh*xh + wh*xl + wl*xh        (fp32 accumulate; the dropped wl*xl term is 2^-16 relative)
-// over three 32-slot k-chunks: k-group g = chunk*4 + lane group covers (dy, colour c) = (g / 3, g % 3) for g < 9 with
-// its 8 slots = 4 columns x 2 frames of patch row r + dy (the 4th column has zero weights), g = 9 is the bias, 10-11
-// are empty - 9 bf16 MFMAs of 16 cycles per cout tile instead of 14 fp32 ones of 32.  Same scheme, and the same
+// over three 32-slot k-chunks: chunk = the tap column dx, lane group = the tap row dy, its 8 slots = 3 colours x 2 frames
+// (+ 2 empty) of patch pixel (r + dy, x + dx); lane group 3 carries the bias in chunk 0 and is empty otherwise - 9 bf16
+// MFMAs of 16 cycles per cout tile instead of 14 fp32 ones of 32.  Same scheme, and the same
 // ~2^-16 relative accuracy before the bf16 rounding of the output, as the fused gray stem (conv3x3_mfma.hip.h,
 // SRC_STEM).  /root/reference/model/unet.py:72 with n_channels = 6 (unet.py:66); channel order of torch.cat([f1, f2]).
 #ifndef FIUNET_RGB_STEM_OCC
@@ -190,47 +190,55 @@ __global__ __launch_bounds__(256, FIUNET_RGB_STEM_OCC) void stem_rgb_split_kerne
     // u1 / u2 != nullptr (fiunet_forward_u8): the uint8 frames [B][3][H][W] are read and normalised right here
     // (preprocess_u8_value: the same fp32 values fiunet_preprocess_u8 would have written), f1 / f2 are unused
     constexpr int CF = 3, TH = 16, TW = 32, PH = TH + 2, PW = TW + 4;
-    constexpr int IMG = PH * PW;                 // dwords of one (colour, hi | lo) patch image
-    constexpr int BUF = 6 * IMG;                 // one patch buffer: 3 colours x (hi, lo); there are two (double-buffered)
-    constexpr int BIAS_OFF = 2 * BUF;            // 8 dwords {1.0, 0}, 0, 0, ... (hi operand of the bias k-group)
-    constexpr int ZERO_OFF = BIAS_OFF + 8;       // 8 zero dwords (its lo operand; both operands of the empty groups)
-    __shared__ __attribute__((aligned(16))) unsigned pd[ZERO_OFF + 8];
+    // Patch image (round 5): PIXEL-major, one 16-B record per patch pixel = {c0, c1, c2, 0} dwords, each dword the bf16 pair
+    // {frame1, frame2} of that colour; a hi image and a lo image per buffer.  MFMA k-chunk = the tap COLUMN dx, lane group
+    // lc = the tap row dy (k-slot lc*8 + 2*colour + frame; slots 6, 7 carry zero weights; lane group 3 = the bias slot): the
+    // lane of output pixel (r, x) reads ONE aligned 16-B record at patch (r + lc, x + dx) per operand and chunk - 6
+    // ds_read_b128 per fragment.  (Round 4's colour-major images made a lane's 8 k-slots 4 consecutive columns of one colour:
+    // a window sliding by one dword per lane, i.e. 24 unaligned ds_read_b32 / ds_read2_b32 per fragment and 6 ds_write_b32 per
+    // staged pixel instead of 2 ds_write_b128.)
+    constexpr int PIX = PH * PW;                 // records of one (hi | lo) patch image
+    constexpr int BUF = 2 * PIX;                 // one patch buffer in records: hi image, lo image; there are two (double-buffered)
+    constexpr int BIAS_REC = 2 * BUF;            // record {1.0 | 0, 0, 0, 0}: hi operand of the bias k-slot (lane group 3, chunk 0)
+    constexpr int ZERO_REC = BIAS_REC + 1;       // zero record: its lo operand, and both operands of lane group 3 in chunks 1, 2
+    __shared__ uint4 pd[ZERO_REC + 1];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l15 = lane & 15, lc = lane >> 4;
 
-    // ---- A operands: this lane's row of every cout tile (packed row lc'*4 + j of tile ct <-> cout lc'*16 + ct*4 + j,
-    //      so that a lane ends up with 16 consecutive couts), 8 k-slots of its lane group, for the three chunks
+    // ---- A operands: this lane's row of every cout tile, the 8 k-slots of its lane group (= tap row dy), per chunk dx.
+    //      Packed row lc'*4 + j of tile ct <-> cout (ct >> 1)*32 + lc'*8 + (ct & 1)*4 + j: an output lane (pixel, lc) then holds
+    //      8 consecutive couts of plane 0 (tiles 0, 1) and 8 of plane 1 (tiles 2, 3) = the 16-B quarter lc of both 64-B plane
+    //      records, so that ONE store instruction writes whole records (1 KiB contiguous per plane), as the conv kernels do
+    //      (round 4 gave a lane 16 consecutive couts: two 16-B stores per lane, each covering half of every record it touched).
     uint4 ah[3][4], al[3][4];
-    unsigned off_h[3], off_l[3], fmul[3];
 #pragma unroll
-    for (int ch = 0; ch < 3; ++ch) {
-        const int g = ch * 4 + lc, dy = g / 3, c = g - dy * 3;
-        off_h[ch] = g < 9 ? (unsigned)((c * 2) * IMG + dy * PW) : (g == 9 ? BIAS_OFF : ZERO_OFF);
-        off_l[ch] = g < 9 ? (unsigned)((c * 2 + 1) * IMG + dy * PW) : ZERO_OFF;
-        fmul[ch] = g < 9 ? 1u : 0u;
+    for (int dx = 0; dx < 3; ++dx) {
 #pragma unroll
         for (int ct = 0; ct < 4; ++ct) {
-            const int cout = (l15 >> 2) * 16 + ct * 4 + (l15 & 3);
+            const int cout = (ct >> 1) * 32 + (l15 >> 2) * 8 + (ct & 1) * 4 + (l15 & 3);
             const float sc = scale[cout];
             unsigned h[4], l[4];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {        // slots 2i (frame 1), 2i + 1 (frame 2) of column dx = i
+            for (int c = 0; c < 4; ++c) {        // slots 2c (frame 1), 2c + 1 (frame 2) of colour c
                 float v0 = 0.f, v1 = 0.f;
-                if (g < 9 && i < 3) {
-                    const int tap = dy * 3 + i;
+                if (lc < 3 && c < 3) {
+                    const int tap = lc * 3 + dx;
                     v0 = w[((tap * 2 * CF) + c) * 64 + cout] * sc;
                     v1 = w[((tap * 2 * CF) + CF + c) * 64 + cout] * sc;
-                } else if (g == 9 && i == 0) {
+                } else if (lc == 3 && dx == 0 && c == 0) {
                     v0 = shift[cout];
                 }
-                h[i] = pack_bf16x2_pk(v0, v1);
-                l[i] = pack_bf16x2_pk(v0 - __uint_as_float(h[i] << 16), v1 - __uint_as_float(h[i] & 0xffff0000u));
+                h[c] = pack_bf16x2_pk(v0, v1);
+                l[c] = pack_bf16x2_pk(v0 - __uint_as_float(h[c] << 16), v1 - __uint_as_float(h[c] & 0xffff0000u));
             }
-            ah[ch][ct] = make_uint4(h[0], h[1], h[2], h[3]);
-            al[ch][ct] = make_uint4(l[0], l[1], l[2], l[3]);
+            ah[dx][ct] = make_uint4(h[0], h[1], h[2], h[3]);
+            al[dx][ct] = make_uint4(l[0], l[1], l[2], l[3]);
         }
     }
-    if (tid < 16) pd[BIAS_OFF + tid] = tid == 0 ? 0x00003f80u : 0u;
+    if (tid == 0) { pd[BIAS_REC] = make_uint4(0x00003f80u, 0u, 0u, 0u); pd[ZERO_REC] = make_uint4(0u, 0u, 0u, 0u); }
+    // this lane's record index within a patch image for fragment (r = 0, half 0), chunk dx = 0; lane group 3 does not move
+    const int lane_rec = lc < 3 ? lc * PW + l15 : 0;
+    const int rec_mul = lc < 3 ? 1 : 0;
 
     const int tilesX = (W + TW - 1) / TW, tilesY = (H + TH - 1) / TH;
     const long long ntiles = (long long)B * tilesX * tilesY;
@@ -238,7 +246,7 @@ __global__ __launch_bounds__(256, FIUNET_RGB_STEM_OCC) void stem_rgb_split_kerne
     // The raw patch of the NEXT tile is requested (into registers) before this tile's fragments run and converted /
     // split / stored into the other of two LDS patch buffers after them: the global round trip of a tile's 18 loads per
     // thread hides under the previous tile's MFMAs, and a tile costs one barrier (round 4 staged and multiplied in turn).
-    constexpr int NI = (IMG + 255) / 256;        // patch pixels per thread
+    constexpr int NI = (PIX + 255) / 256;        // patch pixels per thread
     float r0[NI][CF], r1[NI][CF], dth[NI];
     unsigned okm = 0;
     auto fetch = [&](long long t) __attribute__((always_inline)) {
@@ -252,7 +260,7 @@ __global__ __launch_bounds__(256, FIUNET_RGB_STEM_OCC) void stem_rgb_split_kerne
             const int i = tid + k * 256;
             const int py = i / PW, px = i - py * PW;
             const int y = y0 - 1 + py, x = x0 - 1 + px;
-            const bool ok = (i < IMG) & (y >= 0) & (y < H) & (x >= 0) & (x < W);
+            const bool ok = (i < PIX) & (y >= 0) & (y < H) & (x >= 0) & (x < W);
             okm |= (ok ? 1u : 0u) << k;
             const size_t at = (size_t)min(max(y, 0), H - 1) * W + min(max(x, 0), W - 1);
             dth[k] = dither * stem_dither(y, x);
@@ -264,22 +272,24 @@ __global__ __launch_bounds__(256, FIUNET_RGB_STEM_OCC) void stem_rgb_split_kerne
             }
         }
     };
-    auto stash = [&](unsigned* dst) __attribute__((always_inline)) {
+    auto stash = [&](uint4* dstb) __attribute__((always_inline)) {
 #pragma unroll
         for (int k = 0; k < NI; ++k) {
             const int i = tid + k * 256;
             const bool ok = (okm >> k) & 1u;
+            unsigned h[CF], l[CF];
 #pragma unroll
             for (int c = 0; c < CF; ++c) {
                 float v0 = r0[k][c], v1 = r1[k][c];
                 if (u1) { v0 = preprocess_u8_value((unsigned char)v0); v1 = preprocess_u8_value((unsigned char)v1); }
                 v0 = ok ? v0 + dth[k] : 0.f;   // +d on frame 1, -d on frame 2; the conv's zero padding stays exactly zero
                 v1 = ok ? v1 - dth[k] : 0.f;
-                const unsigned hi = pack_bf16x2_pk(v0, v1);
-                if (i < IMG) {
-                    dst[(c * 2) * IMG + i] = hi;
-                    dst[(c * 2 + 1) * IMG + i] = pack_bf16x2_pk(v0 - __uint_as_float(hi << 16), v1 - __uint_as_float(hi & 0xffff0000u));
-                }
+                h[c] = pack_bf16x2_pk(v0, v1);
+                l[c] = pack_bf16x2_pk(v0 - __uint_as_float(h[c] << 16), v1 - __uint_as_float(h[c] & 0xffff0000u));
+            }
+            if (i < PIX) {
+                dstb[i] = make_uint4(h[0], h[1], h[2], 0u);
+                dstb[PIX + i] = make_uint4(l[0], l[1], l[2], 0u);
             }
         }
     };
@@ -291,36 +301,38 @@ __global__ __launch_bounds__(256, FIUNET_RGB_STEM_OCC) void stem_rgb_split_kerne
         const long long q = t / tilesX;
         const int ty = (int)(q % tilesY), b = (int)(q / tilesY);
         const int y0 = ty * TH, x0 = tx * TW;
-        unsigned* const pb = pd + buf * BUF;
+        uint4* const pb = pd + buf * BUF;
         stash(pb);
         __syncthreads();   // this tile's patch is complete; every wave is past the fragments of the tile before last (same buffer)
         if (t + gridDim.x < ntiles) fetch(t + gridDim.x);
+        // lane group 3: hi operand = the bias record in chunk 0, zeros otherwise; lo operand = zeros
+        const uint4* const ph0 = lc < 3 ? pb + lane_rec : pd + BIAS_REC;
+        const uint4* const pl0 = lc < 3 ? pb + PIX + lane_rec : pd + ZERO_REC;
+        const uint4* const phz = lc < 3 ? pb + lane_rec : pd + ZERO_REC;
         // ---- fragments: wave = 4 tile rows x 2 column halves
 #pragma unroll 2
         for (int f = 0; f < 8; ++f) {
             const int r = wave * 4 + (f >> 1), xc = (f & 1) * 16 + l15;
             const int y = y0 + r, x = x0 + xc;
+            const int o = rec_mul * (r * PW + (f & 1) * 16);
             f32x4 acc[4];
 #pragma unroll
             for (int ct = 0; ct < 4; ++ct) acc[ct] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int ch = 0; ch < 3; ++ch) {
-                const unsigned o = fmul[ch] * (unsigned)(r * PW + xc + buf * BUF);
-                const unsigned* ph = pd + off_h[ch] + o;
-                const unsigned* pl = pd + off_l[ch] + o;
-                const uint4 bh = make_uint4(ph[0], ph[1], ph[2], ph[3]);
-                const uint4 bl = make_uint4(pl[0], pl[1], pl[2], pl[3]);
+            for (int dx = 0; dx < 3; ++dx) {
+                const uint4 bh = (dx == 0 ? ph0 : phz)[o + rec_mul * dx];
+                const uint4 bl = pl0[o + rec_mul * dx];
 #pragma unroll
-                for (int ct = 0; ct < 4; ++ct) mma_chunk<__bf16>(acc[ct], al[ch][ct], bh);
+                for (int ct = 0; ct < 4; ++ct) mma_chunk<__bf16>(acc[ct], al[dx][ct], bh);
 #pragma unroll
-                for (int ct = 0; ct < 4; ++ct) mma_chunk<__bf16>(acc[ct], ah[ch][ct], bl);
+                for (int ct = 0; ct < 4; ++ct) mma_chunk<__bf16>(acc[ct], ah[dx][ct], bl);
 #pragma unroll
-                for (int ct = 0; ct < 4; ++ct) mma_chunk<__bf16>(acc[ct], ah[ch][ct], bh);
+                for (int ct = 0; ct < 4; ++ct) mma_chunk<__bf16>(acc[ct], ah[dx][ct], bh);
             }
             if (y < H && x < W) {
-                // couts lc*16 .. lc*16+15 of this pixel: half of a 64-B plane record
-                char* op = (char*)dst + (size_t)b * H * W * 64 * 2 + blk_off((lc * 16) / 32, y, x, H, W) +
-                           (size_t)((lc * 16) % 32) * 2;
+                // o16[0..7] = couts lc*8 .. +7 (plane 0), o16[8..15] = couts 32 + lc*8 .. +7 (plane 1): quarter lc of both records
+                char* op = (char*)dst + (size_t)b * H * W * 64 * 2 + blk_off(0, y, x, H, W) + lc * 16;
+                const size_t plane_bytes = (size_t)H * W * 64;
                 float o16[16];
 #pragma unroll
                 for (int ct = 0; ct < 4; ++ct)
@@ -328,15 +340,15 @@ __global__ __launch_bounds__(256, FIUNET_RGB_STEM_OCC) void stem_rgb_split_kerne
                     for (int j = 0; j < 4; ++j) o16[ct * 4 + j] = fmaxf(acc[ct][j], 0.f);
                 if constexpr (X2) {
                     const size_t blk = (size_t)2 * H * W * 64;   // bytes from a hi record to its lo record (2 planes per piece)
-                    char* o2 = (char*)dst + (size_t)b * 2 * blk + blk_off((lc * 16) / 32, y, x, H, W) + (size_t)((lc * 16) % 32) * 2;
+                    char* o2 = (char*)dst + (size_t)b * 2 * blk + blk_off(0, y, x, H, W) + lc * 16;
                     float c0[8], c1[8];
 #pragma unroll
                     for (int c = 0; c < 8; ++c) { c0[c] = o16[c]; c1[c] = o16[8 + c]; }
                     x2_split_store(o2, blk, c0);
-                    x2_split_store(o2 + 16, blk, c1);
+                    x2_split_store(o2 + plane_bytes, blk, c1);
                 } else {
                     *reinterpret_cast<uint4*>(op) = chunk_pack<__bf16>(o16);
-                    *reinterpret_cast<uint4*>(op + 16) = chunk_pack<__bf16>(o16 + 8);
+                    *reinterpret_cast<uint4*>(op + plane_bytes) = chunk_pack<__bf16>(o16 + 8);
                 }
             }
         }
