@@ -21,6 +21,8 @@ _PKG = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("FIUNET_LIB") or os.path.join(_PKG, "libfiunet_hip.so")  # FIUNET_LIB: A/B builds
 CSRC = os.path.join(_PKG, "csrc")
 
+ABI_VERSION = 5        # include/fiunet.h FIUNET_ABI_VERSION this binding is written for
+ABI_MIN_COMPAT = 4     # oldest A/B library (FIUNET_LIB) whose shared entry points have today's signatures
 FP32, BF16, BF16X2 = 0, 1, 2   # include/fiunet.h: enum fiunet_precision
 OPT_UNFUSED, OPT_KEEP_ALL, OPT_PAIR_TILES, OPT_GATHER_UPSAMPLE = 1, 2, 8, 16
 OPT_RNE_WEIGHTS, OPT_NO_DITHER = 32, 64
@@ -31,7 +33,7 @@ SYMBOLS = (
     "fiunet_set_options", "fiunet_load_weights", "fiunet_prepare_precision", "fiunet_workspace_bytes", "fiunet_forward",
     "fiunet_min_unsplit_batch",
     "fiunet_forward_strip",
-    "fiunet_workspace_bytes_u8", "fiunet_forward_u8", "fiunet_preprocess_u8",
+    "fiunet_workspace_bytes_u8", "fiunet_forward_u8", "fiunet_forward_u8_strided", "fiunet_preprocess_u8",
     "fiunet_postprocess_u8", "fiunet_debug_read_activation", "fiunet_profile_enable",
     "fiunet_profile_read", "fiunet_metrics_workspace_bytes", "fiunet_psnr_u8", "fiunet_ssim_u8",
     "fiunet_ssim_gauss_workspace_bytes", "fiunet_ssim_gauss_f32",
@@ -60,7 +62,15 @@ def lib() -> ctypes.CDLL:
             "(run `python -c 'import __graft_entry__ as g; g.build()'` or `make -C "
             f"{CSRC}`).  There is no CPU fallback for this path.")
     L = ctypes.CDLL(LIB_PATH)
-    if os.environ.get("FIUNET_LIB"):
+    # the argument lists below are this ABI version's: a library of another version would take misaligned arguments
+    # silently (v4 inserted a parameter into fiunet_debug_read_activation under the same symbol name)
+    L.fiunet_abi_version.restype = ctypes.c_int
+    ver = int(L.fiunet_abi_version())
+    ab = bool(os.environ.get("FIUNET_LIB"))
+    if ver != ABI_VERSION and not (ab and ABI_MIN_COMPAT <= ver < ABI_VERSION):
+        raise RuntimeError(f"{LIB_PATH} implements fiunet ABI v{ver}; this binding is written for v{ABI_VERSION}"
+                           + (f" (A/B libraries from v{ABI_MIN_COMPAT} on are accepted)" if ab else "") + ": rebuild it")
+    if ab:
         # an A/B build of an older source state (tools/ab_bench.py) may predate the newest entry points:
         # bind what it has; calling a missing one still fails loudly (AttributeError)
         have = [n for n in SYMBOLS if hasattr(L, n)]
@@ -93,6 +103,7 @@ def lib() -> ctypes.CDLL:
     L.fiunet_forward.argtypes = [vp, vp, vp, vp, ci, ci, ci, ci, vp, sz, vp]
     L.fiunet_forward_strip.argtypes = [vp, vp, vp, vp, ci, ci, ci, ci, ci, ci, vp, sz, vp]
     L.fiunet_forward_u8.argtypes = [vp, vp, vp, vp, ci, ci, ci, ci, vp, sz, vp]
+    L.fiunet_forward_u8_strided.argtypes = [vp, vp, vp, vp, sz, ci, ci, ci, ci, vp, sz, vp]
     L.fiunet_preprocess_u8.argtypes = [vp, vp, sz, vp]
     L.fiunet_postprocess_u8.argtypes = [vp, vp, sz, vp]
     L.fiunet_debug_read_activation.argtypes = [vp, vp, ci, ci, ci, ci, ci, vp, sz,
@@ -215,11 +226,21 @@ class Context:
                                          workspace.numel(), s), "fiunet_forward_strip")
 
     def forward_u8(self, f1, f2, out, precision, workspace, stream=None):
-        b, _, h, w = f1.shape
+        """`out`: uint8 [B, C, H, W] whose images are contiguous; they may lie further apart than one image (a strided
+        view such as every second frame of the video loop's interleaved result): the fused head writes them in place."""
+        b, c, h, w = f1.shape
         s = torch.cuda.current_stream(f1.device).cuda_stream if stream is None else stream
-        check(lib().fiunet_forward_u8(self._h, f1.data_ptr(), f2.data_ptr(), out.data_ptr(), b, h,
-                                      w, precision, workspace.data_ptr(), workspace.numel(), s),
-              "fiunet_forward_u8")
+        if out.is_contiguous():
+            check(lib().fiunet_forward_u8(self._h, f1.data_ptr(), f2.data_ptr(), out.data_ptr(), b, h,
+                                          w, precision, workspace.data_ptr(), workspace.numel(), s),
+                  "fiunet_forward_u8")
+            return
+        st = out.stride()
+        if tuple(st[1:]) != (h * w, w, 1) or (b > 1 and st[0] < c * h * w):
+            raise ValueError(f"out: every image must be contiguous (strides {tuple(st)} for shape {tuple(out.shape)})")
+        check(lib().fiunet_forward_u8_strided(self._h, f1.data_ptr(), f2.data_ptr(), out.data_ptr(), st[0], b, h,
+                                              w, precision, workspace.data_ptr(), workspace.numel(), s),
+              "fiunet_forward_u8_strided")
 
     def profile_enable(self, on: bool):
         check(lib().fiunet_profile_enable(self._h, 1 if on else 0), "fiunet_profile_enable")

@@ -109,8 +109,11 @@ struct ConvArgs {
     // the slices in order (deterministic) and applies scale/shift/ReLU.
     int ksplit;
     int pair;            // host side only: 8-wave tile-pair kernel where it applies (FIUNET_OPT_PAIR_TILES)
+    int force_tile;      // host side only (diagnostic, fiunet_debug_force_cfg): 0 = choose, 1 = the big tile, 2 = the small one
+    int force_ksplit;    // host side only (diagnostic): 0 = choose, k >= 1 = cut the K loop k ways
     float* kslab;
-    unsigned long long* stamp;  // diagnostic builds (-DFIUNET_STAMP) only: 8 cycle sums per wave
+    unsigned long long* stamp;  // diagnostic builds (-DFIUNET_STAMP / -DFIUNET_CLOCK) only: one 128-B record (16 cycle sums) per wave
+    unsigned stamp_cap;         //   records the buffer holds (waves beyond it do not write)
     const float* head_w; // fused 1x1 head: [head_nc][64]
     const float* head_b; // [head_nc]
     float* head_out;     // fp32 NCHW [B][head_nc][H][W]
@@ -120,6 +123,8 @@ struct ConvArgs {
     const uint8_t* u2;
     uint8_t* head_out_u8;     // fused head: uint8 NCHW output instead of head_out (nullptr: fp32 logits)
     int head_nc;
+    size_t head_img_stride;   // elements from one image of head_out / head_out_u8 to the next (contiguous: head_nc * H * W;
+                              // fiunet_forward_u8_strided: the video loop's interleaved destination, every second frame)
 };
 
 template <typename T> struct Elem;
@@ -484,6 +489,14 @@ template <int BN, int TH, int TW, int MODE> struct ConvTile {
     static constexpr int SPARE_BYTES =
         (MODE == SRC_CONCAT_UP && LR_PIECES * 1024 > W_BYTES) ? LR_PIECES * 1024 - W_BYTES : 0;
     static constexpr int W_STRIDE = W_BYTES + SPARE_BYTES;  // slot 1 = slot 0 + W_STRIDE
+    // Depth of the weight ring.  Two slots (W(step+1) lands under the MFMAs of `step`) are what the 64 x 128 wave tiles
+    // have LDS for at two workgroups per CU - and all they need: a step is 96 MFMAs per wave and the weights of a layer
+    // that fills the chip are L2 hits.  The 64 x 64 wave tiles are the small-problem configuration (fiunet.hip,
+    // choose_conv_cfg): one or two workgroups per CU, every (cout tile, K slice) streams weights nobody else has touched
+    // (Infinity Cache / HBM latency) and a step is 48 MFMAs - there the ring is FOUR deep (W(step+3) requested at the top of
+    // `step`: a whole plane ahead), which costs 24 KiB of LDS nobody is using.
+    // (three with the fused stem, whose patch and parked weights take 7.5 KiB of the 80)
+    static constexpr int W_SLOTS = (TH * TW / 16 / (4 / (BN / 64)) == 4 && SPARE_BYTES == 0) ? (src_is_stem(MODE) ? 3 : 4) : 2;
     // SRC_STEM: raw patch of both frames, (TH+4) x (TW+4) pixels, after the ring: bf16 dwords {frame1,
     // frame2}, the hi and the lo part of a patch row side by side, [row][hi | lo][PATCH_W].  The row pitch
     // of 2 * PATCH_W = 72 dwords makes rows py and py+2 - read together by lane groups 0 and 1 of a
@@ -491,7 +504,7 @@ template <int BN, int TH, int TW, int MODE> struct ConvTile {
     // and lo images of pitch 36 put rows py, py+1 only 4 banks apart: 2-way conflicts on 12 of 16 lanes).
     static constexpr int PATCH_W = TW + 4, PATCH_H = TH + 4, PATCH_PITCH = 2 * PATCH_W;
     static_assert(!src_is_stem(MODE) || (2 * PATCH_PITCH) % 32 == 16, "patch pitch: lane groups 0/1 must not share banks");
-    static constexpr int PATCH_OFF = IN_BYTES + 2 * W_BYTES + SPARE_BYTES;
+    static constexpr int PATCH_OFF = IN_BYTES + W_SLOTS * W_BYTES + SPARE_BYTES;
     // The operand of the bias k-slot - PATCH_W dwords {1.0, 0} followed by PATCH_W zero dwords (its lo
     // part), which all lanes of lane group 3 read at the same address (a broadcast) - lives in the
     // row-pitch filler of in-tile row 0 (pixels TW+2 .. TWP-1: never written or read in this mode), so
@@ -519,7 +532,11 @@ template <int BN, int TH, int TW, int MODE> struct ConvTile {
 // short-K full-resolution layers, whose prologue/epilogue share is large, a third resident wave per
 // SIMD keeps the MFMA pipe fed while the other two gather or store).
 constexpr int conv_wave_frags(int BN, int TH, int TW) { return TH * TW / 16 / (4 / (BN / 64)); }
-constexpr int conv_occupancy(int BN, int TH, int TW) { return conv_wave_frags(BN, TH, TW) == 4 ? 3 : 2; }
+// (a 64 x 64 wave tile whose workgroup needs more than a third of the CU's LDS - the fused-stem gather - stays at two)
+constexpr int conv_occupancy(int BN, int TH, int TW, int lds_bytes = 0)
+{
+    return conv_wave_frags(BN, TH, TW) == 4 && lds_bytes * 3 <= 160 * 1024 ? 3 : 2;
+}
 
 // ---- accumulator set-up and epilogue shared by the conv kernels ---------------------------------
 // Eval-mode BatchNorm is folded on both sides of the K loop: its scale into the packed weights
@@ -579,19 +596,19 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x4 (&acc)[4]
     constexpr bool PERM = sizeof(T) == 2;
     const int wbase_c = ct * BN + wc * 64;  // first cout of this wave
     if constexpr (EPI == EPI_SPLITK) {
-        float* const slab = a.kslab + (size_t)split * a.B * aH * aW * a.Cout;
+        // raw fp32 partial sums of this K slice, in FRAGMENT order: slab[split][tile][wave][m * NF + n][lane] as float4,
+        // so every store instruction of a wave writes 1 KiB contiguous (round 6; the pixel-major slab of rounds 1-5 was
+        // written 16 B at a time with a stride of Cout floats: 29 % of a K-split kernel's wave time was this epilogue,
+        // gpurun_out/r6b/stamp_b1_256_bf16.txt).  splitk_finalize_tile_kernel reads it back in the same order.
+        const int tile = (((b * a.tilesY) + y0 / TH) * a.tilesX + x0 / TW) * a.nct + ct;
+        const int ntile = a.B * a.tilesY * a.tilesX * a.nct;
+        const int wave = wp * (BN / 64) + wc;
+        float4* o = reinterpret_cast<float4*>(a.kslab) + ((((size_t)split * ntile + tile) * 4 + wave) * (4 * NF)) * 64 + (lc * 16 + l15);
 #pragma unroll
-        for (int n = 0; n < NF; ++n) {
-            const int y = y0 + wp * ROWS_W + n / FR;
-            const int x = x0 + (n % FR) * 16 + l15;
-            if (y < aH && x < aW) {
-                float* o = slab + (((size_t)b * aH + y) * aW + x) * a.Cout + wbase_c;
+        for (int m = 0; m < 4; ++m)
 #pragma unroll
-                for (int m = 0; m < 4; ++m)
-                    *reinterpret_cast<float4*>(o + conv_cout_ofs<T>(m, lc)) =
-                        make_float4(acc[m][n][0], acc[m][n][1], acc[m][n][2], acc[m][n][3]);
-            }
-        }
+            for (int n = 0; n < NF; ++n)
+                o[(m * NF + n) * 64] = make_float4(acc[m][n][0], acc[m][n][1], acc[m][n][2], acc[m][n][3]);
         return;
     }
     float hw[HNC > 0 ? HNC : 1][4][4];
@@ -618,7 +635,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x4 (&acc)[4]
         // by a transposing reduction (v_permlane16_swap / v_permlane32_swap: 6 swaps instead of 16
         // bpermutes, same (lc0 + lc1) + (lc2 + lc3) order), which leaves fragments nb, nb + 1 complete
         // in lane group lc: all 64 lanes store, 2 dwords each.
-        static_assert(HNC == 0 || NF == 8, "head reduction is written for 8 fragments per wave");
+        static_assert(HNC == 0 || NF == 8 || NF == 4, "head reduction is written for 8 or 4 fragments per wave");
         const float floor_v = a.relu ? 0.f : -__builtin_inff();
         float hb[HNC];
 #pragma unroll
@@ -636,26 +653,47 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x4 (&acc)[4]
                     for (int j = 0; j < 4; ++j) relu_fma(sum, acc[m][n][j], floor_v, hw[c][m][j]);
                 hs[n] = sum;
             }
-            float t[4], u[2];
+            if constexpr (NF == 4) {
+                // 64 x 64 wave tiles (small problems): four fragments, one per lane group after the reduction.  Two
+                // xor-shuffles per fragment give every lane (g0 + g1) + (g2 + g3) of its pixel - the association of
+                // the transposing reduction below (fp addition commutes), so the output bits do not depend on the tile
+                float full[NF];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {  // rows 0, 2: fragment i; rows 1, 3: fragment i + 4
-                const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(hs[i]), __float_as_uint(hs[i + 4]), false, false);
-                t[i] = __uint_as_float(r[0]) + __uint_as_float(r[1]);
-            }
-#pragma unroll
-            for (int j = 0; j < 2; ++j) {  // rows 0, 1: t[j]; rows 2, 3: t[j + 2]
-                const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(t[j]), __float_as_uint(t[j + 2]), false, false);
-                u[j] = __uint_as_float(r[0]) + __uint_as_float(r[1]);
-            }
-#pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                const int n = nb + j;
+                for (int n = 0; n < NF; ++n) {
+                    const float p = hs[n] + __shfl_xor(hs[n], 16);
+                    full[n] = p + __shfl_xor(p, 32);
+                }
+                const float mine = lc == 0 ? full[0] : (lc == 1 ? full[1] : (lc == 2 ? full[2] : full[3]));
+                const int n = lc;
                 const int y = y0 + wp * ROWS_W + n / FR;
                 const int x = x0 + (n % FR) * 16 + l15;
                 if (y < aH && x < aW) {
-                    const size_t o = (((size_t)b * HNC + c) * aH + y) * aW + x;
-                    if (a.head_out_u8) a.head_out_u8[o] = postprocess_u8_value(u[j] + hb[c]);
-                    else a.head_out[o] = u[j] + hb[c];
+                    const size_t o = (size_t)b * a.head_img_stride + ((size_t)c * aH + y) * aW + x;
+                    if (a.head_out_u8) a.head_out_u8[o] = postprocess_u8_value(mine + hb[c]);
+                    else a.head_out[o] = mine + hb[c];
+                }
+            } else {
+                float t[4], u[2];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {  // rows 0, 2: fragment i; rows 1, 3: fragment i + 4
+                    const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(hs[i]), __float_as_uint(hs[(i + 4) % NF]), false, false);
+                    t[i] = __uint_as_float(r[0]) + __uint_as_float(r[1]);
+                }
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {  // rows 0, 1: t[j]; rows 2, 3: t[j + 2]
+                    const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(t[j]), __float_as_uint(t[j + 2]), false, false);
+                    u[j] = __uint_as_float(r[0]) + __uint_as_float(r[1]);
+                }
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    const int n = nb + j;
+                    const int y = y0 + wp * ROWS_W + n / FR;
+                    const int x = x0 + (n % FR) * 16 + l15;
+                    if (y < aH && x < aW) {
+                        const size_t o = (size_t)b * a.head_img_stride + ((size_t)c * aH + y) * aW + x;
+                        if (a.head_out_u8) a.head_out_u8[o] = postprocess_u8_value(u[j] + hb[c]);
+                        else a.head_out[o] = u[j] + hb[c];
+                    }
                 }
             }
         }
@@ -853,7 +891,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x4 (&acc)[4]
 }
 
 template <typename T, int BN, int TH, int TW, int MODE, int EPI>
-__global__ __launch_bounds__(256, conv_occupancy(BN, TH, TW)) void conv3x3_mfma_kernel(const ConvArgs a)
+__global__ __launch_bounds__(256, conv_occupancy(BN, TH, TW, ConvTile<BN, TH, TW, MODE>::LDS_BYTES)) void conv3x3_mfma_kernel(const ConvArgs a)
 {
     using Tile = ConvTile<BN, TH, TW, MODE>;
     constexpr int PL = Elem<T>::PL;
@@ -865,7 +903,7 @@ __global__ __launch_bounds__(256, conv_occupancy(BN, TH, TW)) void conv3x3_mfma_
     static_assert(NF == 8 || NF == 4, "wave tile must be 64 couts x 128 or 64 pixels");
     static_assert(TH == ROWS_W * WAVES_P && ROWS_W * FR == NF, "tile does not split over the waves");
     static_assert(EPI != EPI_POOL || ROWS_W % 2 == 0, "pooled epilogue: a wave owns whole row pairs");
-    static_assert(Tile::LDS_BYTES * conv_occupancy(BN, TH, TW) <= 160 * 1024, "LDS per CU");
+    static_assert(Tile::LDS_BYTES * conv_occupancy(BN, TH, TW, Tile::LDS_BYTES) <= 160 * 1024, "LDS per CU");
     constexpr int HNC = EPI == EPI_HEAD ? 1 : (EPI == EPI_HEAD3 ? 3 : 0);  // fused-head classes
     static_assert(HNC == 0 || BN == 64, "fused head needs all 64 couts in one wave");
     static_assert(MODE == SRC_DIRECT || MODE == SRC_CONCAT_UP || MODE == SRC_STEM || MODE == SRC_DIRECT_X2 ||
@@ -906,8 +944,39 @@ __global__ __launch_bounds__(256, conv_occupancy(BN, TH, TW)) void conv3x3_mfma_
     const int l15 = lane & 15, lc = lane >> 4;
     const int wc = wave % WAVES_C, wp = wave / WAVES_C;
 
+#ifdef FIUNET_STAMP
+    // diagnostic build: per-wave s_memtime sums per phase.  Slots: [0] total [1] prologue (whole) [2] MFMA phases
+    // [3] end-of-step wait + barrier [4] plane-boundary gather (rest) [5] epilogue [6] upsample staging DMA + wait
+    // [7] upsample interpolation [8] record count; the prologue again, split (round 6): [9] kernel entry -> accumulators
+    // initialised (argument + BatchNorm-shift loads) [10] W(0) issue + LDS read offsets [11] gather walk (per-tile
+    // offsets / masks, padding zeroed; CONCAT_UP: the lerp tables) [12] fused stem: weights + patch staging + barrier
+    // [13] first in-tile: DMA issue (fused stem: the stem's evaluation) [14] wait for W(0) + the in-tile (vmcnt(0))
+    // [15] the barrier that publishes them.  PSTAMP pins the code of a sub-phase in place (sched_barrier), so the
+    // prologue of this build is not scheduled as the shipped one is: [1] / [0] of a build WITHOUT the split is the
+    // share to quote, the split says where inside it the time sits.
+    unsigned long long st_sum[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long st_t0 = __builtin_amdgcn_s_memtime(), st_prev = st_t0;
+#ifdef FIUNET_STAMP_PROLOG
+    unsigned long long st_pprev = st_t0;
+#define PSTAMP(slot) do { __builtin_amdgcn_sched_barrier(0); const unsigned long long t_ = __builtin_amdgcn_s_memtime(); \
+                          st_sum[slot] += t_ - st_pprev; st_pprev = t_; __builtin_amdgcn_sched_barrier(0); } while (0)
+#else
+#define PSTAMP(slot) do {} while (0)
+#endif
+#define STAMP(slot) do { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); \
+                         st_sum[slot] += t_ - st_prev; st_prev = t_; } while (0)
+#define STAMP_UP(slot) STAMP(slot)
+#else
+#define STAMP(slot) do {} while (0)
+#define STAMP_UP(slot) do {} while (0)
+#define PSTAMP(slot) do {} while (0)
+#endif
     f32x4 acc[4][NF];
     conv_acc_init<T, BN, TH, TW, EPI>(a, acc, ct, wc, lc);  // BatchNorm shift (scale is in the weights)
+#ifdef FIUNET_STAMP_PROLOG
+    asm volatile("" :: "v"(acc[3][NF - 1][3]), "v"(acc[0][0][0]));  // the shift loads have landed
+#endif
+    PSTAMP(9);
 
     // per-lane LDS read offsets (everything else is an immediate)
     const int a_off = (wc * 64 + l15) * 64 + ((lc ^ swz(l15)) << 4);  // within a weight ring slot
@@ -928,6 +997,7 @@ __global__ __launch_bounds__(256, conv_occupancy(BN, TH, TW)) void conv3x3_mfma_
     // ---- weight stream: each wave moves NW 1-KiB pieces (16 LDS rows) per step by LDS-DMA.  The
     //      LDS image is lane-linear, so the XOR swizzle goes on the per-lane SOURCE chunk. --------
     constexpr int NW = Tile::W_BYTES / 1024 / 4;
+    constexpr int NSLOT = Tile::W_SLOTS;   // ring depth: W(step + NSLOT - 1) is requested at the top of `step`
     // Piece j of this wave = packed rows r0 .. r0+15 with r0 = (wave * NW + j) * 16; 16 divides BN, so a
     // piece lies inside one tap: its source offset is a wave-uniform part (added to the SGPR base) plus
     // ONE per-lane register shared by all pieces (row within the piece, swizzled 16-B chunk).
@@ -942,7 +1012,7 @@ __global__ __launch_bounds__(256, conv_occupancy(BN, TH, TW)) void conv3x3_mfma_
         }
         const char* wsrc = wbase + ((size_t)(pl * 9 + kx * 3) * a.Cout) * 64;  // packed [plane][kx][ky][cout]
         const unsigned dst = __builtin_amdgcn_readfirstlane(
-            lds_w_addr + (unsigned)((step & 1) * Tile::W_STRIDE + wave * NW * 1024));
+            lds_w_addr + (unsigned)((step % NSLOT) * Tile::W_STRIDE + wave * NW * 1024));
 #pragma unroll
         for (int j = 0; j < NW; ++j) {
             const int r0 = (wave * NW + j) * 16, tap = r0 / BN;  // tap = ky within the step
@@ -951,7 +1021,19 @@ __global__ __launch_bounds__(256, conv_occupancy(BN, TH, TW)) void conv3x3_mfma_
     };
     // W(0) goes out first (slot 0; slot 1 + spare is the idle staging area for plane 0), ahead of the
     // in-tile address math below, so its round trip runs under those ~200 instructions
+#ifndef FIUNET_DIAG_FREE_PROLOGUE
     issue_w(0);
+#endif
+#ifdef FIUNET_DIAG_NO_WSTREAM
+    if (nsteps > 1) issue_w(1);   // both ring slots hold real weights (realistic operand data, hence realistic power); nothing streams afterwards
+#else
+    if constexpr (NSLOT > 2) {    // deeper ring: the weights of steps 1 .. NSLOT-2 go out with W(0)
+#pragma unroll
+        for (int k = 1; k < NSLOT - 1; ++k)
+            if (k < nsteps) issue_w(k);
+    }
+#endif
+    PSTAMP(10);
 
     // ---- in-tile gather (a): planes stored as-is in an NHWC tensor go by LDS-DMA: piece j = 16
     //      consecutive LDS rows (pixels) x 64 B, address = plane base in SGPRs + a 32-bit per-lane
@@ -970,12 +1052,14 @@ __global__ __launch_bounds__(256, conv_occupancy(BN, TH, TW)) void conv3x3_mfma_
     // and a plane's gather costs ~8 instructions per piece; the pooled / concat / head / split-K
     // variants and the 64-cout tiles (12-14 pieces per wave), which are at the 256-VGPR limit,
     // rebuild it per plane from three registers (see pm_* below; hoisting there spills).
-    constexpr bool HOIST = (MODE == SRC_DIRECT && BN == 128 && EPI == EPI_PLAIN);   // (the two-piece epilogue with it: 3 spilled registers)
+    // (64 x 64 wave tiles - the small-problem configuration - have 64 accumulator registers less: every direct variant hoists)
+    constexpr bool HOIST = (MODE == SRC_DIRECT && BN == 128 && EPI == EPI_PLAIN) ||   // (the two-piece epilogue with it: 3 spilled registers)
+                           (NF == 4 && DIRECT);
     // Rolling window of in-tile rows across the three ky taps of a step (24 instead of 36 fragment
     // reads per step): bf16 32-wide tiles.  The fp32 instantiations (4 MFMAs per fragment pair keep
     // more operands in flight) and the 16-wide tiles have no registers to spare for the extra row
     // and re-read every row for every tap instead; same tap order, same sums.
-    constexpr bool ROLL = sizeof(T) == 2 && FR == 2 && EPI != EPI_SPLITK;
+    constexpr bool ROLL = sizeof(T) == 2 && FR == 2 && (EPI != EPI_SPLITK || NF == 4);
     constexpr int NPW = (NPIECE + 3) / 4;
     unsigned in_off[HOIST ? NPW : 1];
     const unsigned plane_bytes = (unsigned)(aH * aW) * 64u;
@@ -1053,16 +1137,6 @@ __global__ __launch_bounds__(256, conv_occupancy(BN, TH, TW)) void conv3x3_mfma_
         });
     };
 
-#ifdef FIUNET_STAMP
-    unsigned long long st_sum[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    unsigned long long st_t0 = __builtin_amdgcn_s_memtime(), st_prev = st_t0;
-#define STAMP(slot) do { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); \
-                         st_sum[slot] += t_ - st_prev; st_prev = t_; } while (0)
-#define STAMP_UP(slot) STAMP(slot)
-#else
-#define STAMP(slot) do {} while (0)
-#define STAMP_UP(slot) do {} while (0)
-#endif
     // ---- in-tile gather (b): bilinearly upsampled planes.  The low-res source tile (<= LRH x LRW
     //      pixels of this plane) is DMA-ed into the idle weight slot + spare region, then every
     //      thread interpolates its chunks LDS -> LDS: one memory round trip per plane instead of
@@ -1113,7 +1187,8 @@ __global__ __launch_bounds__(256, conv_occupancy(BN, TH, TW)) void conv3x3_mfma_
     auto gather_plane_up = [&](int plane, int idle_slot) __attribute__((always_inline)) {
         constexpr int LRP = Tile::LRP, LRH = Tile::LRH;
         // idle slot 0: [slot0 | spare]; idle slot 1: [spare | slot1]
-        const int stg_off = idle_slot == 0 ? 0 : Tile::W_BYTES;
+        // (deeper rings exist only where the staging tile fits one slot: no spare region, any idle slot will do)
+        const int stg_off = NSLOT > 2 ? idle_slot * Tile::W_STRIDE : (idle_slot == 0 ? 0 : Tile::W_BYTES);
         const char* const lsrc = (const char*)a.src1 + (size_t)b * a.lowH * a.lowW * a.C1 * sizeof(T) +
                                  (size_t)(plane - p0) * a.lowH * a.lowW * 64;
         int opq = 0;
@@ -1444,17 +1519,27 @@ __global__ __launch_bounds__(256, conv_occupancy(BN, TH, TW)) void conv3x3_mfma_
         else gather_plane_up(plane, idle_slot);
     };
 
-    // diagnostic build (-DFIUNET_STAMP): where does a wave's time go?  [0] total [1] prologue
-    // [2] MFMA phases [3] end-of-step wait+barrier [4] plane-boundary gather (rest) [5] epilogue
-    // [6] upsample staging DMA + wait [7] upsample interpolation   (s_memtime ticks)
+    PSTAMP(11);
     if constexpr (STEM) {
         stem_load(stem_w0);
         stage_patch();
         __syncthreads();
+        PSTAMP(12);
     }
+    // timing diagnostics (results are garbage, only the clock matters; round 6, review item 1): -DFIUNET_DIAG_FREE_PROLOGUE drops W(0) and
+    // the first in-tile gather of every kernel that fetches it by DMA - the kernel as it would run if a cross-tile prefetch
+    // had delivered both for free (the upper bound of lever (a)); -DFIUNET_DIAG_NO_WSTREAM drops the whole weight stream - the
+    // upper bound of weights held in LDS for the kernel's lifetime (lever (b))
+#ifdef FIUNET_DIAG_FREE_PROLOGUE
+    if constexpr (STEM || MODE == SRC_CONCAT_UP) gather_plane(pbeg, 1, true);
+#else
     gather_plane(pbeg, 1, true);
+#endif
+    PSTAMP(13);
     lds_dma_wait_all();
+    PSTAMP(14);
     __syncthreads();
+    PSTAMP(15);
     STAMP(1);
 #ifdef FIUNET_CLOCK
     // diagnostic build (-DFIUNET_CLOCK, no other stamp executes): shader cycles (s_memtime) and constant 100 MHz ticks
@@ -1472,8 +1557,14 @@ __global__ __launch_bounds__(256, conv_occupancy(BN, TH, TW)) void conv3x3_mfma_
         for (int kx = 0; kx < 3; ++kx, ++step) {
             // W(step) and the in-tile of `plane` are resident.  Stream W(step+1) into the other
             // ring slot (its last readers passed the barrier that ended step-1).
-            if (step + 1 < nsteps) issue_w(step + 1);
-            const char* wcur = lds_w + (step & 1) * Tile::W_STRIDE + a_off;
+            // (deeper ring: W(step + NSLOT - 1) into the slot step - 1 was read from; its readers passed that step's barrier)
+#ifndef FIUNET_DIAG_NO_WSTREAM
+            const bool w_issued = step + NSLOT - 1 < nsteps;
+            if (w_issued) issue_w(step + NSLOT - 1);
+#else
+            const bool w_issued = false;
+#endif
+            const char* wcur = lds_w + (step % NSLOT) * Tile::W_STRIDE + a_off;
             // this wave's in-tile rows 0 .. ROWS_W+1 at column offset kx: row i serves tap ky for the
             // output row i - ky, so every fragment is read once and used by up to three taps
             // Last step of a plane whose successor arrives by plain LDS-DMA: after the load of the last
@@ -1509,7 +1600,7 @@ __global__ __launch_bounds__(256, conv_occupancy(BN, TH, TW)) void conv3x3_mfma_
                         // in registers): once every wave is here the in-tile is dead and the next
                         // plane's DMA goes out, 64 MFMAs ahead of the boundary
                         __syncthreads();
-                        gather_plane(plane + 1, step & 1, false);
+                        gather_plane(plane + 1, step % NSLOT, false);
                     }
 #pragma unroll
                     for (int m = 0; m < 4; ++m)
@@ -1552,7 +1643,7 @@ __global__ __launch_bounds__(256, conv_occupancy(BN, TH, TW)) void conv3x3_mfma_
             STAMP(2);
             if (kx == 2 && gather_next && !early) {
                 __syncthreads();  // every wave is done with this plane's in-tile and with W(step)
-                gather_plane(plane + 1, step & 1, false);
+                gather_plane(plane + 1, step % NSLOT, false);
                 lds_dma_wait_all();
                 __syncthreads();
                 // fused x2 stem: every wave has read plane 0's parked weights for the last time (lo piece): plane 1's
@@ -1560,7 +1651,16 @@ __global__ __launch_bounds__(256, conv_occupancy(BN, TH, TW)) void conv3x3_mfma_
                 if constexpr (STEM && X2) { if (plane + 1 == 2) stem_park(1); }
                 STAMP(4);
             } else {
-                lds_dma_wait_all();   // this wave's pieces of W(step+1) landed
+                // this wave's pieces of W(step+1) landed.  Deeper ring: the (NSLOT - 2) * NW requests issued after them (the
+                // weights of the steps beyond) may stay in flight - loads return in order, so a counted wait is exact -
+                // unless this step issued the next plane's in-tile (early gather), which the next step reads: then everything
+                if (NSLOT > 2 && !early && w_issued) {
+                    if constexpr (NSLOT == 4 && NW == 3) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+                    else if constexpr (NSLOT == 3 && NW == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+                    else lds_dma_wait_all();
+                } else {
+                    lds_dma_wait_all();
+                }
                 __syncthreads();      // ... and so have everyone else's
                 STAMP(3);
             }
@@ -1572,11 +1672,12 @@ __global__ __launch_bounds__(256, conv_occupancy(BN, TH, TW)) void conv3x3_mfma_
         asm volatile("" :: "v"(acc[3][NF - 1][3]));  // keep the stamp behind the last MFMA
         __builtin_amdgcn_sched_barrier(0);
         const unsigned long long ck_t1 = __builtin_amdgcn_s_memtime(), ck_r1 = __builtin_amdgcn_s_memrealtime();
-        if (a.stamp && lane == 0) {  // one private 64-B record per wave, read by nothing else in the kernel
-            unsigned long long* rec = a.stamp + ((size_t)blockIdx.x * 4 + wave) * 8;
+        const unsigned st_idx = blockIdx.x * 4u + (unsigned)wave;
+        if (a.stamp && lane == 0 && st_idx < a.stamp_cap) {  // one private 128-B record per wave, read by nothing else in the kernel
+            unsigned long long* rec = a.stamp + (size_t)st_idx * 16;
             rec[0] = ck_t1 - ck_t0;
             rec[1] = ck_r1 - ck_r0;
-            rec[6] = 1ull;
+            rec[8] = 1ull;
         }
     }
 #endif
@@ -1584,15 +1685,78 @@ __global__ __launch_bounds__(256, conv_occupancy(BN, TH, TW)) void conv3x3_mfma_
 #ifdef FIUNET_STAMP
     STAMP(5);
     st_sum[0] = st_prev - st_t0;
-    if (a.stamp && lane == 0) {  // one private 64-B record per wave: no atomics, no contention
-        unsigned long long* rec = a.stamp + ((size_t)blockIdx.x * 4 + wave) * 8;
+    const unsigned st_idx = blockIdx.x * 4u + (unsigned)wave;
+    if (a.stamp && lane == 0 && st_idx < a.stamp_cap) {  // one private 128-B record per wave: no atomics, no contention
+        unsigned long long* rec = a.stamp + (size_t)st_idx * 16;
 #pragma unroll
-        for (int k = 0; k < 6; ++k) rec[k] = st_sum[k];
-        rec[6] = 1ull;
-        rec[7] = (st_sum[6] << 32) | (st_sum[7] & 0xffffffffull);
+        for (int k = 0; k < 16; ++k) rec[k] = k == 8 ? 1ull : st_sum[k];
     }
 #endif
 }
 
+// Second pass of a K-split conv (small problems: fewer workgroups than the chip has CUs, e.g. the deep levels of the ONE
+// 256x256 pair the reference runs, /root/reference/model/inference.py:29): one workgroup per (tile, cout tile) adds the
+// `ksplit` fp32 partial-sum slices in index order - deterministic, no atomics - on top of the BatchNorm shift, and then
+// runs the conv kernel's OWN epilogue on the sums: ReLU, the blocked store, the fused MaxPool2d(2) copy (EPI_POOL) and the
+// two-piece split of precision "bf16x2", all from one code path (rounds 1-5: a pixel-major slab, an element-wise
+// finalize kernel and a separate max-pool launch).  The slab is read in the fragment order the conv wrote it in
+// (conv_epilogue, EPI_SPLITK): 1 KiB contiguous per load instruction.
+template <typename T, int BN, int TH, int TW, int EPI, bool X2>
+__global__ __launch_bounds__(256) void splitk_finalize_tile_kernel(const ConvArgs a)
+{
+    static_assert(EPI == EPI_PLAIN || EPI == EPI_POOL, "a fused head is never K-split");
+    constexpr int WAVES_C = BN / 64;
+    constexpr int NF = conv_wave_frags(BN, TH, TW);
+    int t = blockIdx.x;                       // = the conv's logical tile index (its slab record)
+    const int tile = t;
+    const int ct = t % a.nct; t /= a.nct;
+    const int tx = t % a.tilesX; t /= a.tilesX;
+    const int ty = t % a.tilesY;
+    const int b = t / a.tilesY;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int l15 = lane & 15, lc = lane >> 4;
+    const int wc = wave % WAVES_C, wp = wave / WAVES_C;
+    const int ntile = a.B * a.tilesY * a.tilesX * a.nct;
+    f32x4 acc[4][NF];
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+#pragma unroll
+        for (int n = 0; n < NF; ++n) acc[m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const float4* p = reinterpret_cast<const float4*>(a.kslab) + (((size_t)tile * 4 + wave) * (4 * NF)) * 64 + lane;
+    const size_t slice = (size_t)ntile * 4 * (4 * NF) * 64;
+    // slices in chunks of four: the 4 x NF loads of a cout tile are independent and issued together (the pass is a chain
+    // of memory round trips, not bandwidth: one slice per trip took ~0.5 us per slice), the additions stay in slice order
+    const int ks = a.ksplit;
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+        const float4* pm = p + (size_t)m * NF * 64;
+        for (int s0 = 0; s0 < ks; s0 += 4, pm += 4 * slice) {
+            float4 q[4][NF];
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                if (s0 + j < ks) {
+#pragma unroll
+                    for (int n = 0; n < NF; ++n) q[j][n] = pm[j * slice + n * 64];
+                }
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                if (s0 + j < ks) {
+#pragma unroll
+                    for (int n = 0; n < NF; ++n) {
+                        acc[m][n][0] += q[j][n].x; acc[m][n][1] += q[j][n].y; acc[m][n][2] += q[j][n].z; acc[m][n][3] += q[j][n].w;
+                    }
+                }
+        }
+    }
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {   // BatchNorm shift (the scale is folded into the weights)
+        const float4 sh = *reinterpret_cast<const float4*>(a.shift + ct * BN + wc * 64 + conv_cout_ofs<T>(m, lc));
+#pragma unroll
+        for (int n = 0; n < NF; ++n) {
+            acc[m][n][0] += sh.x; acc[m][n][1] += sh.y; acc[m][n][2] += sh.z; acc[m][n][3] += sh.w;
+        }
+    }
+    conv_epilogue<T, BN, TH, TW, EPI, X2>(a, acc, b, ty * TH, tx * TW, ct, 0, wc, wp, l15, lc);
+}
 
 }  // namespace fiunet

@@ -42,7 +42,8 @@ int fail(int code, const std::string& msg)
 
 constexpr int NCONV = 18;
 constexpr size_t kSlabBytes = 64u << 20;  // split-K slab: ksplit * B*H*W*Cout * 4 <= ~50 MB by construction
-[[maybe_unused]] constexpr size_t kStampWaves = 4 * 40000;  // diagnostic stamp records
+[[maybe_unused]] constexpr size_t kStampWaves = 4 * 40000;  // diagnostic stamp records (128 B each); launches with more waves leave the rest unrecorded
+[[maybe_unused]] constexpr size_t kStampRec = 16;              // u64 slots per record
 // conv index = 2*block + {0,1}; blocks: inc, down1..4, up1..4 (state-dict order)
 const char* const kBlockPrefix[9] = {
     "unet.inc", "unet.down1.maxpool_conv.1", "unet.down2.maxpool_conv.1",
@@ -241,6 +242,8 @@ struct fiunet_ctx {
     void* stem_w_split = nullptr;  // gray stem weights x BatchNorm scale as bf16 hi/lo pairs [2][64][32] (fused stem)
     unsigned long long* stamps = nullptr;  // per-wave cycle records (diagnostic -DFIUNET_STAMP builds)
     int stamp_layer = -1;
+    int force_tile[NCONV] = {0};     // diagnostic overrides of choose_conv_cfg per conv (fiunet_debug_force_cfg; tools/cfg_sweep.py)
+    int force_ksplit[NCONV] = {0};
     std::vector<void*> owned;
     // per-layer HIP-event profiling (fiunet_profile_*): NCONV+1 events per recorded forward
     bool profiling = false;
@@ -271,6 +274,8 @@ void free_weights(fiunet_ctx* ctx)
     ctx->owned.clear();
     ctx->loaded = false;
     ctx->x2_ready = false;
+    for (auto& c : ctx->conv) c.w_x2 = nullptr;     // (fiunet_prepare_precision reuses a non-null copy)
+    for (auto& c : ctx->convt) c.w_x2 = nullptr;
 }
 
 thread_local std::string* g_name_out = nullptr;  // where the next conv launch reports its kernel
@@ -337,69 +342,7 @@ int launch_pair_cfg(ConvArgs a, hipStream_t s)
     return FIUNET_OK;
 }
 
-// K-split rule of one conv (launch_conv_maybe_split and fiunet_min_unsplit_batch share it): `nblk` workgroups
-// without a split, `nplanes` K-loop planes, B images of H x W with Cout output channels.  Returns the number of K
-// slices (1 = no split).  Fewer workgroups than CUs: cut K as well.  The cut changes the fp32 summation order, so it
-// must not depend on the batch size for frames whose batches are compared bit for bit (a video's ragged last chunk,
-// B=1 vs B=8 at 1080p): layers with >= 64 workgroups PER IMAGE keep round 1's rule (split below 128 workgroups in
-// total, which such a layer never has for B >= 2 - a SINGLE pair with 64..127 workgroups per image, e.g. the deepest
-// level of a 720p frame, does split); small frames, where a single pair is K-split anyway, split below 256.
-inline int ksplit_rule(long long nblk, int nplanes, int B, int H, int W, int Cout)
-{
-    int ksplit = (int)std::min<long long>(std::min(nplanes / 2, 16), (256 + nblk - 1) / nblk);
-    while (ksplit > 1 && (size_t)ksplit * B * H * W * Cout * 4 > kSlabBytes) --ksplit;
-    const long long thr = nblk / B < 64 ? 256 : 128;
-    return (nblk < thr && ksplit > 1) ? ksplit : 1;
-}
-
-// pair kernel: direct sources, plain / pooled epilogue, enough tile pairs to fill the 256 CUs
-template <typename T, int BN, int TH, int TW, int MODE, int EPI>
-constexpr bool pair_capable() { return MODE == SRC_DIRECT && (EPI == EPI_PLAIN || EPI == EPI_POOL) && BN == 128; }
-inline unsigned grid_for(size_t n);
-
-// Small problems (fewer workgroups than CUs, e.g. the deep levels of a single 256x256 pair,
-// which is the only size the reference ever runs): cut the K loop over `ksplit` workgroups, then
-// reduce + scale/shift/ReLU (+ pool) in a finalize pass.  Deterministic (slices added in order).
-template <typename T, int BN, int TH, int TW, int MODE, int EPI>
-int launch_conv_maybe_split(ConvArgs a, hipStream_t s)
-{
-    constexpr bool X2 = src_is_x2(MODE);   // precision bf16x2: two-piece operands and output, 3 virtual planes per plane
-    if constexpr (!src_is_stem(MODE) && (EPI == EPI_PLAIN || EPI == EPI_POOL)) {
-        const long long nblk = (long long)a.B * ((a.W + TW - 1) / TW) * ((a.H + TH - 1) / TH) * (a.Cout / BN);
-        const int nplanes = (a.C0 + a.C1) / Elem<T>::PL * (X2 ? 3 : 1);
-        const int ksplit = ksplit_rule(nblk, nplanes, a.B, a.H, a.W, a.Cout);
-        if (ksplit > 1 && a.kslab && a.dst) {
-            ConvArgs k = a;
-            k.ksplit = ksplit;
-            int rc = launch_conv_cfg<T, BN, TH, TW, MODE, EPI_SPLITK>(k, s);
-            if (rc) return rc;
-            const size_t n = (size_t)a.B * a.H * a.W * (a.Cout / Elem<T>::NE);
-            hipLaunchKernelGGL((splitk_finalize_kernel<T>), dim3(grid_for(n)), dim3(256), 0, s, a.kslab,
-                               ksplit, (const float*)nullptr, a.shift, (T*)a.dst, a.B, a.H, a.W, a.Cout, a.relu, X2 ? 1 : 0);
-            HIP_TRY(hipGetLastError());
-            if constexpr (EPI == EPI_POOL && X2) {
-                const size_t np2 = (size_t)a.B * (a.Cout / 32) * (a.H / 2) * (a.W / 2) * 4;
-                hipLaunchKernelGGL(x2_maxpool2_kernel, dim3(grid_for(np2)), dim3(256), 0, s, (const char*)a.dst,
-                                   (char*)a.pool_dst, a.B, a.H, a.W, a.Cout);
-                HIP_TRY(hipGetLastError());
-            }
-            if constexpr (EPI == EPI_POOL && !X2) {
-                const size_t np = (size_t)a.B * (a.H / 2) * (a.W / 2) * (a.Cout * sizeof(T) / 16);
-                hipLaunchKernelGGL((maxpool2_kernel<T>), dim3(grid_for(np)), dim3(256), 0, s,
-                                   (const T*)a.dst, (T*)a.pool_dst, a.B, a.H, a.W, a.Cout);
-                HIP_TRY(hipGetLastError());
-            }
-            if (g_name_out) *g_name_out += "+splitk" + std::to_string(ksplit);
-            return FIUNET_OK;
-        }
-    }
-    if constexpr (pair_capable<T, BN, TH, TW, MODE, EPI>()) {
-        const long long ntiles = (long long)a.B * ((a.W + TW - 1) / TW) * ((a.H + TH - 1) / TH);
-        if (a.pair && a.C1 == 0 && (ntiles + 1) / 2 * (a.Cout / BN) >= 256)  // (its gather knows one source)
-            return launch_pair_cfg<T, BN, TH, TW, EPI>(a, s);
-    }
-    return launch_conv_cfg<T, BN, TH, TW, MODE, EPI>(a, s);
-}
+inline unsigned grid_for(size_t n) { return (unsigned)std::min<size_t>((n + 255) / 256, 256 * 32); }
 
 inline long long padded_area(int H, int W, int TH, int TW)
 {
@@ -413,6 +356,124 @@ inline bool prefer_wide(int H, int W, int THw, int TWw, int THn, int TWn)
 {
     const long long wide = padded_area(H, W, THw, TWw), narrow = padded_area(H, W, THn, TWn);
     return wide * 32 <= narrow * 33;
+}
+
+// ---- tile shape and K split of one conv launch ---------------------------------------------------------------------
+// Two tile families.  BIG (rounds 1-5, tuned on the 1080p workload): 64 couts x 16x32 / 32x16 pixels or 128 couts x 8x32 /
+// 16x16 pixels, every wave a 64 x 128 tile (128 accumulator registers), two workgroups per CU.  SMALL (round 6): 64 couts x
+// 8x32 pixels, every wave a 64 x 64 tile, three workgroups per CU - twice (Cout = 64) or four times (Cout >= 128, where two
+// cout tiles replace one) the workgroups of the big tile, each with half the MFMAs per step.  On a problem that fills the
+// chip the big tile wins (fewer fragment reads per MFMA, half the halo and weight re-reads: measured in rounds 1-3); on a
+// problem with fewer big-tile workgroups than the chip has CUs - every layer of the ONE 256x256 pair that is the reference's
+// only operating point (/root/reference/model/inference.py:29,101-122) - half the SIMDs have no wave at all and the small
+// tile halves the time (fp32: MFMA-bound; bf16: the serial chain of a workgroup's steps).  The K loop (planes) can be cut
+// over `ksplit` workgroups as well (raw fp32 partial sums to a slab + splitk_finalize_tile_kernel): worth it only where a
+// workgroup's serial K loop is longer than the extra launch (~5 us) - the deep levels.
+//
+// Neither choice changes a bit of the result as long as ksplit stays the same: the summation order of an output element
+// is (plane, kx, ky) in every tile shape, the fused head reduces in the same association, and a K cut only moves where the
+// partial sums meet (fp32, in slice order).  The cut itself does change the fp32 summation order, so it must not depend on
+// the batch size for frames whose batches are compared bit for bit (a video's ragged last chunk, B=1 vs B=8 at 1080p):
+// layers with >= 64 big-tile workgroups PER IMAGE are cut only below 128 workgroups in total, which such a layer never has
+// for B >= 2 (a SINGLE pair with 64..127 workgroups per image, e.g. the deepest level of a 720p frame, is); small frames,
+// where a single pair is cut anyway, below 256.  fiunet_min_unsplit_batch answers from the same function.
+struct TileShape { int BN, TH, TW; };
+struct ConvCfg { bool small; int ksplit; };
+
+inline TileShape big_tile(int H, int W, int Cout)
+{
+    if (Cout == 64) return prefer_wide(H, W, 16, 32, 32, 16) ? TileShape{64, 16, 32} : TileShape{64, 32, 16};
+    return prefer_wide(H, W, 8, 32, 16, 16) ? TileShape{128, 8, 32} : TileShape{128, 16, 16};
+}
+constexpr TileShape kSmallTile = {64, 8, 32};
+
+inline long long tile_blocks(const TileShape& t, int B, int H, int W, int Cout)
+{
+    return (long long)B * ((W + t.TW - 1) / t.TW) * ((H + t.TH - 1) / t.TH) * (Cout / t.BN);
+}
+
+// Estimated duration (ns) of one conv launch (+ its finalize pass when the K loop is cut).  Constants from the per-layer
+// sweep of tools/cfg_sweep.py on MI355X (profiles/r06_cfg_sweep_*.txt): a dependent dispatch costs ~4.5 us whatever it
+// does; a workgroup's prologue + epilogue ~2.5 us; a step (one plane x kx, three taps) is MFMA time at one wave per SIMD -
+// bf16 0.73 us for a 64 x 128 wave tile, half of it for 64 x 64, fp32 8x that - plus ~0.25 us of waits and barriers, and
+// co-resident workgroups share the SIMD's MFMA pipe.
+inline double conv_cost_ns(bool fp32, bool small, long long nblk, int nplanes, int ksplit, bool x2)
+{
+    const double t_launch = 4500.0, t_fix = 2500.0, t_ovh = 250.0;
+    const int occ = small ? 3 : 2;
+    const double mfma_step = (fp32 ? 5850.0 : 730.0) * (small ? 0.5 : 1.0);
+    const long long nwg = nblk * ksplit;
+    const int steps = (nplanes + ksplit - 1) / ksplit * 3;
+    const long long slots = 256LL * occ;
+    const long long rounds = (nwg + slots - 1) / slots;
+    // workgroups sharing a CU in a full round share its MFMA pipes; a lone partial round runs at its own occupancy
+    const double share = rounds > 1 ? (double)occ : (double)std::max<long long>(1, (nwg + 255) / 256);
+    double ns = t_launch + rounds * (t_fix + steps * (mfma_step * share + t_ovh));
+    if (ksplit > 1) ns += t_launch + 1200.0 + 120.0 * ksplit * (x2 ? 1.5 : 1.0);
+    return ns;
+}
+
+// `splittable`: plain / pooled epilogue with a slab to write to (never the fused stem or the fused head).
+// force_small: -1 = choose, 0 / 1 = debug override; force_ksplit: 0 = choose, k >= 1 = debug override.
+inline ConvCfg choose_conv_cfg(bool fp32, bool x2, int B, int H, int W, int Cin, int Cout, bool splittable,
+                               int force_small = -1, int force_ksplit = 0)
+{
+    const int PL = fp32 ? 16 : 32;
+    const int nplanes = Cin / PL * (x2 ? 3 : 1);
+    const TileShape big = big_tile(H, W, Cout);
+    const long long nblk_big = tile_blocks(big, B, H, W, Cout), nblk_small = tile_blocks(kSmallTile, B, H, W, Cout);
+    ConvCfg best{false, 1};
+    if (nblk_big >= 256 && force_small < 0 && force_ksplit <= 0) return best;   // the chip is full: the tuned tile, whole K loop
+    const bool may_split = splittable && nblk_big < (nblk_big / B < 64 ? 256 : 128);
+    double best_ns = 1e30;
+    for (int small = 0; small < 2; ++small) {
+        if (force_small >= 0 && small != force_small) continue;
+        const TileShape& t = small ? kSmallTile : big;
+        const long long nblk = small ? nblk_small : nblk_big;
+        for (int k = 1; k <= 32; k *= 2) {
+            if (force_ksplit > 0 ? k != force_ksplit : (k > 1 && !may_split)) continue;
+            if (k > 1 && (!splittable || k > nplanes)) continue;
+            // slab: ksplit slices of the PADDED output in fp32
+            if (k > 1 && (size_t)k * nblk * t.BN * t.TH * t.TW * 4 > kSlabBytes) continue;
+            const double ns = conv_cost_ns(fp32, small != 0, nblk, nplanes, k, x2);
+            if (ns < best_ns) { best_ns = ns; best = ConvCfg{small != 0, k}; }
+        }
+    }
+    return best;
+}
+
+// pair kernel: direct sources, plain / pooled epilogue, enough tile pairs to fill the 256 CUs
+template <typename T, int BN, int TH, int TW, int MODE, int EPI>
+constexpr bool pair_capable() { return MODE == SRC_DIRECT && (EPI == EPI_PLAIN || EPI == EPI_POOL) && BN == 128; }
+
+// One conv launch in a given tile shape; ksplit > 1: the K loop (planes) cut over `ksplit` workgroups that store raw
+// fp32 partial sums, then splitk_finalize_tile_kernel adds them in slice order (deterministic) and runs the epilogue.
+template <typename T, int BN, int TH, int TW, int MODE, int EPI>
+int launch_conv_maybe_split(ConvArgs a, hipStream_t s, int ksplit)
+{
+    constexpr bool X2 = src_is_x2(MODE);   // precision bf16x2: two-piece operands and output, 3 virtual planes per plane
+    if constexpr (!src_is_stem(MODE) && (EPI == EPI_PLAIN || EPI == EPI_POOL)) {
+        if (ksplit > 1 && a.kslab && a.dst) {
+            ConvArgs k = a;
+            k.ksplit = ksplit;
+            int rc = launch_conv_cfg<T, BN, TH, TW, MODE, EPI_SPLITK>(k, s);
+            if (rc) return rc;
+            k.tilesX = (a.W + TW - 1) / TW;
+            k.tilesY = (a.H + TH - 1) / TH;
+            k.nct = a.Cout / BN;
+            const long long ntile = (long long)a.B * k.tilesX * k.tilesY * k.nct;
+            hipLaunchKernelGGL((splitk_finalize_tile_kernel<T, BN, TH, TW, EPI, X2>), dim3((unsigned)ntile), dim3(256), 0, s, k);
+            HIP_TRY(hipGetLastError());
+            if (g_name_out) *g_name_out += "+splitk" + std::to_string(ksplit);
+            return FIUNET_OK;
+        }
+    }
+    if constexpr (pair_capable<T, BN, TH, TW, MODE, EPI>()) {
+        const long long ntiles = (long long)a.B * ((a.W + TW - 1) / TW) * ((a.H + TH - 1) / TH);
+        if (a.pair && a.C1 == 0 && (ntiles + 1) / 2 * (a.Cout / BN) >= 256)  // (its gather knows one source)
+            return launch_pair_cfg<T, BN, TH, TW, EPI>(a, s);
+    }
+    return launch_conv_cfg<T, BN, TH, TW, MODE, EPI>(a, s);
 }
 
 PlanOpts plan_opts(const fiunet_ctx* ctx, int H, int W, int precision)
@@ -439,16 +500,21 @@ PlanOpts plan_opts(const fiunet_ctx* ctx, int H, int W, int precision)
 
 template <typename T, int MODE, int EPI> int launch_conv_shape(const ConvArgs& a, hipStream_t s)
 {
+    constexpr bool splittable_kind = !src_is_stem(MODE) && (EPI == EPI_PLAIN || EPI == EPI_POOL);
+    if (a.Cout != 64 && a.Cout % 128 != 0) return fail(FIUNET_ERR_INVALID_ARG, "Cout must be 64 or k*128");
+    if ((EPI == EPI_HEAD || EPI == EPI_HEAD3) && a.Cout != 64) return fail(FIUNET_ERR_INVALID_ARG, "fused head needs Cout == 64");
+    const ConvCfg cfg = choose_conv_cfg(sizeof(T) == 4, src_is_x2(MODE), a.B, a.H, a.W, a.C0 + a.C1, a.Cout,
+                                        splittable_kind && a.kslab && a.dst, a.force_tile - 1, a.force_ksplit);
+    if (cfg.small) return launch_conv_maybe_split<T, 64, 8, 32, MODE, EPI>(a, s, cfg.ksplit);
     if (a.Cout == 64) {
         const bool wide = prefer_wide(a.H, a.W, 16, 32, 32, 16);
-        return wide ? launch_conv_maybe_split<T, 64, 16, 32, MODE, EPI>(a, s)
-                    : launch_conv_maybe_split<T, 64, 32, 16, MODE, EPI>(a, s);
+        return wide ? launch_conv_maybe_split<T, 64, 16, 32, MODE, EPI>(a, s, cfg.ksplit)
+                    : launch_conv_maybe_split<T, 64, 32, 16, MODE, EPI>(a, s, cfg.ksplit);
     }
     if constexpr (EPI != EPI_HEAD && EPI != EPI_HEAD3) {
-        if (a.Cout % 128 != 0) return fail(FIUNET_ERR_INVALID_ARG, "Cout must be 64 or k*128");
         const bool wide = prefer_wide(a.H, a.W, 8, 32, 16, 16);
-        return wide ? launch_conv_maybe_split<T, 128, 8, 32, MODE, EPI>(a, s)
-                    : launch_conv_maybe_split<T, 128, 16, 16, MODE, EPI>(a, s);
+        return wide ? launch_conv_maybe_split<T, 128, 8, 32, MODE, EPI>(a, s, cfg.ksplit)
+                    : launch_conv_maybe_split<T, 128, 16, 16, MODE, EPI>(a, s, cfg.ksplit);
     }
     return fail(FIUNET_ERR_INVALID_ARG, "fused head needs Cout == 64");
 }
@@ -471,21 +537,24 @@ template <typename T> int launch_conv(const ConvArgs& a, int mode, int epi, hipS
 
     }
     if constexpr (sizeof(T) == 2) {
-        if (mode == SRC_STEM && epi == EPI_POOL && a.Cout == 64)  // 16x32 tiles only (LDS budget)
-            return launch_conv_cfg<T, 64, 16, 32, SRC_STEM, EPI_POOL>(a, s);
-        if (mode == SRC_STEM_X2 && epi == EPI_POOL && a.Cout == 64)
-            return launch_conv_cfg<T, 64, 16, 32, SRC_STEM_X2, EPI_POOL>(a, s);
+        if ((mode == SRC_STEM || mode == SRC_STEM_X2) && epi == EPI_POOL && a.Cout == 64) {  // 32-wide tiles only (the patch layout)
+            const bool small = choose_conv_cfg(false, mode == SRC_STEM_X2, a.B, a.H, a.W, 64, 64, false, a.force_tile - 1, 0).small;
+            if (mode == SRC_STEM)
+                return small ? launch_conv_cfg<T, 64, 8, 32, SRC_STEM, EPI_POOL>(a, s)
+                             : launch_conv_cfg<T, 64, 16, 32, SRC_STEM, EPI_POOL>(a, s);
+            return small ? launch_conv_cfg<T, 64, 8, 32, SRC_STEM_X2, EPI_POOL>(a, s)
+                         : launch_conv_cfg<T, 64, 16, 32, SRC_STEM_X2, EPI_POOL>(a, s);
+        }
     }
     return fail(FIUNET_ERR_INVALID_ARG, "unsupported gather/epilogue combination");
 }
-
-inline unsigned grid_for(size_t n) { return (unsigned)std::min<size_t>((n + 255) / 256, 256 * 32); }
 
 // The band [y_origin, y_origin + H) of an image of Hg rows (un-tiled: y_origin = 0, Hg = H).
 template <typename T>
 int forward_impl(fiunet_ctx* ctx, const float* f1, const float* f2, float* out, int B, int H,
                  int W, char* ws, const Plan& p, hipStream_t s, int y_origin, int Hg,
-                 const uint8_t* u1 = nullptr, const uint8_t* u2 = nullptr, uint8_t* out_u8 = nullptr)
+                 const uint8_t* u1 = nullptr, const uint8_t* u2 = nullptr, uint8_t* out_u8 = nullptr,
+                 size_t out_img_stride = 0 /* elements between images of out / out_u8; 0 = contiguous */)
 {
     // u1/u2 (uint8 frames) replace f1/f2 only where the stem is fused into conv 1's gather; out_u8 replaces
     // out only where the head is fused into the last conv's epilogue (fiunet_forward_u8 decides)
@@ -534,8 +603,9 @@ int forward_impl(fiunet_ctx* ctx, const float* f1, const float* f2, float* out, 
             // the RGB bf16 network stay bit-identical fused vs unfused); the fp32 network keeps the exact kernel
             if constexpr (sizeof(T) == 2) {
                 const long long ntiles = (long long)B * ((H + 15) / 16) * ((W + 31) / 32);
-                // persistent workgroups, one tile after the other: exactly as many as are resident at once (153 registers
-                // -> 3 waves per SIMD -> 3 workgroups per CU); with 1024 the last 256 ran a second round on a third of the chip
+                // persistent workgroups, one tile after the other: exactly as many as are resident at once
+                // (FIUNET_RGB_STEM_OCC = 2 per CU, the kernel's __launch_bounds__: 176 registers); with more than that the
+                // surplus ran a second round on a fraction of the chip
                 dim3 g2((unsigned)std::min<long long>(ntiles, 256 * FIUNET_RGB_STEM_OCC));
                 hipLaunchKernelGGL(stem_rgb_split_kernel<false>, g2, dim3(256), 0, s, f1, f2, (const float*)cw.w_f32, cw.scale,
                                    cw.shift, (__bf16*)act(0), B, H, W, stem_dither_amp, u1, u2);
@@ -572,6 +642,8 @@ int forward_impl(fiunet_ctx* ctx, const float* f1, const float* f2, float* out, 
         // accumulate in the same order to stay bit-identical with it
         a.kslab = i == NCONV - 1 ? nullptr : (float*)(ws + p.slab_off);
         a.stamp = (ctx->stamps && i == ctx->stamp_layer) ? ctx->stamps : nullptr;
+        a.stamp_cap = (unsigned)kStampWaves;
+        a.force_tile = ctx->force_tile[i]; a.force_ksplit = ctx->force_ksplit[i];
         a.dst = act(i);
         int mode = kMode[i];
         a.src0 = act(kSrc0[i]);
@@ -654,6 +726,7 @@ int forward_impl(fiunet_ctx* ctx, const float* f1, const float* f2, float* out, 
         if (i == NCONV - 1 && !unfused) {  // fuse OutConv (unet.py:60) into the last epilogue
             epi = ctx->cf == 1 ? EPI_HEAD : EPI_HEAD3;
             a.head_w = ctx->head_w; a.head_b = ctx->head_b; a.head_out = out; a.head_out_u8 = out_u8; a.head_nc = ctx->cf;
+            a.head_img_stride = out_img_stride ? out_img_stride : (size_t)ctx->cf * H * W;
             if (!(ctx->flags & FIUNET_OPT_KEEP_ALL)) a.dst = nullptr;
         }
         g_name_out = ev ? &ctx->layer_name[i] : nullptr;
@@ -686,7 +759,7 @@ int forward_impl(fiunet_ctx* ctx, const float* f1, const float* f2, float* out, 
 // the pooled copy).  FIUNET_OPT_KEEP_ALL keeps every activation for the read-back; no ablation path.
 int forward_x2(fiunet_ctx* ctx, const float* f1, const float* f2, float* out, int B, int H, int W, char* ws,
                const Plan& p, hipStream_t s, int y_origin, int Hg, uint8_t* out_u8, const uint8_t* u1 = nullptr,
-               const uint8_t* u2 = nullptr)
+               const uint8_t* u2 = nullptr, size_t out_img_stride = 0)
 {
     using T = __bf16;
     if (!ctx->x2_ready)
@@ -751,6 +824,8 @@ int forward_x2(fiunet_ctx* ctx, const float* f1, const float* f2, float* out, in
         a.ksplit = 1;
         a.kslab = i == NCONV - 1 ? nullptr : (float*)(ws + p.slab_off);   // small problems: K-split like the other paths
         a.stamp = (ctx->stamps && i == ctx->stamp_layer) ? ctx->stamps : nullptr;
+        a.stamp_cap = (unsigned)kStampWaves;
+        a.force_tile = ctx->force_tile[i]; a.force_ksplit = ctx->force_ksplit[i];
         a.dst = act(i);
         a.src0 = act(kSrc0[i]);
         a.C0 = ctx->cout[kSrc0[i]];                // REAL channels: the kernel knows both pieces of a tensor
@@ -808,6 +883,7 @@ int forward_x2(fiunet_ctx* ctx, const float* f1, const float* f2, float* out, in
         if (i == NCONV - 1) {
             epi = ctx->cf == 1 ? EPI_HEAD : EPI_HEAD3;
             a.head_w = ctx->head_w; a.head_b = ctx->head_b; a.head_out = out; a.head_out_u8 = out_u8; a.head_nc = ctx->cf;
+            a.head_img_stride = out_img_stride ? out_img_stride : (size_t)ctx->cf * H * W;
             if (!keep_all) a.dst = nullptr;
         }
         g_name_out = ev ? &ctx->layer_name[i] : nullptr;
@@ -1015,11 +1091,11 @@ int fiunet_load_weights(fiunet_ctx* ctx, int n, const char* const* names,
         const std::vector<char> zeros(256, 0);
         if ((rc = dev_upload(ctx, zeros.data(), zeros.size(), &ctx->zero_page))) return rc;
 #if defined(FIUNET_STAMP) || defined(FIUNET_CLOCK)
-        {   // one 64-B record per wave of the largest launch (B=8 1080p: 32 640 workgroups)
+        {   // one 128-B record per wave of the largest launch (B=8 1080p: 32 640 workgroups); the kernels bound their index
             void* d = nullptr;
-            HIP_TRY(hipMalloc(&d, kStampWaves * 64));
+            HIP_TRY(hipMalloc(&d, kStampWaves * kStampRec * 8));
             ctx->owned.push_back(d);
-            HIP_TRY(hipMemset(d, 0, kStampWaves * 64));
+            HIP_TRY(hipMemset(d, 0, kStampWaves * kStampRec * 8));
             ctx->stamps = (unsigned long long*)d;
         }
 #endif
@@ -1037,15 +1113,18 @@ int fiunet_prepare_precision(fiunet_ctx* ctx, int precision)
     if (precision != FIUNET_BF16X2 || ctx->x2_ready) return FIUNET_OK;   // fp32 / bf16 copies are made by the load
     HIP_TRY(hipSetDevice(ctx->device));
     // two-piece weights [wh | wl], packed on the device from the fp32 copy (BatchNorm scale folded in): ~69 MB more
+    // (a copy that a failed earlier attempt already allocated is packed again in place: a retry allocates nothing twice)
     auto pack = [&](const void* w32, int cin, int cout, int convt, void** out) -> int {
         const size_t n = (size_t)2 * cin * (convt ? 4 : 9) * cout;
-        void* d = nullptr;
-        HIP_TRY(hipMalloc(&d, n * 2));
-        ctx->owned.push_back(d);
+        void* d = *out;
+        if (!d) {
+            HIP_TRY(hipMalloc(&d, n * 2));
+            ctx->owned.push_back(d);
+            *out = d;
+        }
         hipLaunchKernelGGL(x2_pack_weights_kernel, dim3(grid_for(n)), dim3(256), 0, 0, (const float*)w32,
                            (unsigned short*)d, cin, cout, convt);
         HIP_TRY(hipGetLastError());
-        *out = d;
         return FIUNET_OK;
     };
     int rc;
@@ -1069,22 +1148,17 @@ int fiunet_min_unsplit_batch(const fiunet_ctx* ctx, int H, int W, int precision)
         g_err = "fiunet_min_unsplit_batch before fiunet_load_weights";
         return 0;
     }
-    const int PL = precision == FIUNET_FP32 ? 16 : 32;
     int hs[5] = {H}, ws[5] = {W};
     for (int k = 1; k < 5; ++k) { hs[k] = hs[k - 1] / 2; ws[k] = ws[k - 1] / 2; }
-    const bool fused_stem = plan_opts(ctx, H, W, precision).fused_stem;
+    const PlanOpts po = plan_opts(ctx, H, W, precision);
     for (int B = 1; B <= 64; ++B) {
         bool split = false;
-        for (int i = 1; i < NCONV - 1 && !split; ++i) {   // conv 0 = stem kernel, conv 17 is never cut (fused head)
-            if (i == 1 && fused_stem) continue;            // SRC_STEM launches are never cut
-            const int h = hs[kLevel[i]], w = ws[kLevel[i]], cout = ctx->cout[i];
-            // the tile the launch would pick (launch_conv_shape)
-            int BN, TH, TW;
-            if (cout == 64) { BN = 64; const bool wide = prefer_wide(h, w, 16, 32, 32, 16); TH = wide ? 16 : 32; TW = wide ? 32 : 16; }
-            else { BN = 128; const bool wide = prefer_wide(h, w, 8, 32, 16, 16); TH = wide ? 8 : 16; TW = wide ? 32 : 16; }
-            const long long nblk = (long long)B * ((w + TW - 1) / TW) * ((h + TH - 1) / TH) * (cout / BN);
-            const int nplanes = ctx->conv[i].cin / PL * (precision == FIUNET_BF16X2 ? 3 : 1);
-            split = ksplit_rule(nblk, nplanes, B, h, w, cout) > 1;
+        // conv 0 = stem kernel; conv 17 is never cut (its fused-head form cannot be, and the forwards give it no slab on
+        // the ablation / read-back paths either, so that both accumulate in the same order)
+        for (int i = 1; i < NCONV - 1 && !split; ++i) {
+            if (i == 1 && po.fused_stem) continue;            // SRC_STEM launches are never cut
+            split = choose_conv_cfg(precision == FIUNET_FP32, precision == FIUNET_BF16X2, B, hs[kLevel[i]], ws[kLevel[i]],
+                                    ctx->conv[i].cin, ctx->cout[i], true, ctx->force_tile[i] - 1, ctx->force_ksplit[i]).ksplit > 1;
         }
         if (!split) return B;
     }
@@ -1166,6 +1240,13 @@ int fiunet_forward_u8(fiunet_ctx* ctx, const uint8_t* frame1, const uint8_t* fra
                       int B, int H, int W, int precision, void* workspace, size_t workspace_bytes,
                       void* stream)
 {
+    return fiunet_forward_u8_strided(ctx, frame1, frame2, out, 0, B, H, W, precision, workspace, workspace_bytes, stream);
+}
+
+int fiunet_forward_u8_strided(fiunet_ctx* ctx, const uint8_t* frame1, const uint8_t* frame2, uint8_t* out,
+                              size_t out_image_stride, int B, int H, int W, int precision, void* workspace,
+                              size_t workspace_bytes, void* stream)
+{
     if (!ctx || !frame1 || !frame2 || !out || !workspace)
         return fail(FIUNET_ERR_INVALID_ARG, "NULL argument");
     if (!ctx->loaded) return fail(FIUNET_ERR_NOT_LOADED, "fiunet_forward before fiunet_load_weights");
@@ -1173,7 +1254,10 @@ int fiunet_forward_u8(fiunet_ctx* ctx, const uint8_t* frame1, const uint8_t* fra
     if (!base) return fail(H < 16 || W < 16 ? FIUNET_ERR_BAD_SHAPE : FIUNET_ERR_INVALID_ARG, "bad shape");
     bool in_f32, out_f32;
     u8_buffers(ctx, H, W, precision, &in_f32, &out_f32);
-    const size_t n = (size_t)B * ctx->cf * H * W, fb = align256(n * 4);
+    const size_t img = (size_t)ctx->cf * H * W;
+    if (out_image_stride == 0) out_image_stride = img;
+    if (out_image_stride < img) return fail(FIUNET_ERR_INVALID_ARG, "out_image_stride smaller than one image");
+    const size_t n = (size_t)B * img, fb = align256(n * 4);
     if (workspace_bytes < base + ((in_f32 ? 2 : 0) + (out_f32 ? 1 : 0)) * fb)
         return fail(FIUNET_ERR_WORKSPACE, "workspace too small");
     if ((uintptr_t)workspace & 255) return fail(FIUNET_ERR_INVALID_ARG, "workspace not 256-B aligned");
@@ -1194,14 +1278,20 @@ int fiunet_forward_u8(fiunet_ctx* ctx, const uint8_t* frame1, const uint8_t* fra
     const uint8_t* u1 = in_f32 ? nullptr : frame1;
     const uint8_t* u2 = in_f32 ? nullptr : frame2;
     uint8_t* ou = out_f32 ? nullptr : out;
+    // the fused head writes the (possibly strided) uint8 destination itself; the fp32 staging buffer is contiguous
+    const size_t hs = out_f32 ? 0 : out_image_stride;
     if (precision == FIUNET_BF16X2)
-        rc = forward_x2(ctx, a, b, o, B, H, W, ws, p, s, 0, H, ou, u1, u2);
+        rc = forward_x2(ctx, a, b, o, B, H, W, ws, p, s, 0, H, ou, u1, u2, hs);
     else if (precision == FIUNET_BF16)
-        rc = forward_impl<__bf16>(ctx, a, b, o, B, H, W, ws, p, s, 0, H, u1, u2, ou);
+        rc = forward_impl<__bf16>(ctx, a, b, o, B, H, W, ws, p, s, 0, H, u1, u2, ou, hs);
     else
-        rc = forward_impl<float>(ctx, a, b, o, B, H, W, ws, p, s, 0, H, u1, u2, ou);
+        rc = forward_impl<float>(ctx, a, b, o, B, H, W, ws, p, s, 0, H, u1, u2, ou, hs);
     if (rc) return rc;
-    return out_f32 ? fiunet_postprocess_u8(o, out, n, stream) : FIUNET_OK;
+    if (!out_f32) return FIUNET_OK;
+    if (out_image_stride == img) return fiunet_postprocess_u8(o, out, n, stream);
+    for (int i = 0; i < B; ++i)   // (ablation / read-back configurations only: one elementwise launch per image)
+        if ((rc = fiunet_postprocess_u8(o + (size_t)i * img, out + (size_t)i * out_image_stride, img, stream))) return rc;
+    return FIUNET_OK;
 }
 
 static inline int ssim_tiles(int H, int W, int* tiles_x)
@@ -1348,31 +1438,47 @@ int fiunet_postprocess_u8(const float* in, uint8_t* out, size_t n, void* stream)
     return FIUNET_OK;
 }
 
+// diagnostic (not part of the ABI, no declaration in include/fiunet.h): override choose_conv_cfg for one conv (1..17) of
+// this context - tile: 0 = choose, 1 = big, 2 = small; ksplit: 0 = choose, k >= 1 = cut the K loop k ways where the launch
+// can be cut.  tools/cfg_sweep.py times every candidate of every layer with it; layer < 0 clears all overrides.
+int fiunet_debug_force_cfg(fiunet_ctx* ctx, int layer, int tile, int ksplit)
+{
+    if (!ctx || layer >= NCONV || tile < 0 || tile > 2 || ksplit < 0 || ksplit > 32)
+        return fail(FIUNET_ERR_INVALID_ARG, "fiunet_debug_force_cfg: bad arguments");
+    if (layer < 0) {
+        for (int i = 0; i < NCONV; ++i) ctx->force_tile[i] = ctx->force_ksplit[i] = 0;
+        return FIUNET_OK;
+    }
+    ctx->force_tile[layer] = tile;
+    ctx->force_ksplit[layer] = ksplit;
+    return FIUNET_OK;
+}
+
 #if defined(FIUNET_STAMP) || defined(FIUNET_CLOCK)
 // diagnostic builds only (not part of the ABI): stamp ONE stage per forward; read = sums over waves
 int fiunet_debug_stamp_layer(fiunet_ctx* ctx, int layer)
 {
     ctx->stamp_layer = layer;
     HIP_TRY(hipDeviceSynchronize());
-    HIP_TRY(hipMemset(ctx->stamps, 0, kStampWaves * 64));
+    HIP_TRY(hipMemset(ctx->stamps, 0, kStampWaves * kStampRec * 8));
     return FIUNET_OK;
 }
-int fiunet_debug_stamps(fiunet_ctx* ctx, unsigned long long* out /* [8] */)
+int fiunet_debug_stamps(fiunet_ctx* ctx, unsigned long long* out /* [16] */)
 {
     HIP_TRY(hipDeviceSynchronize());
-    std::vector<unsigned long long> h(kStampWaves * 8);
-    HIP_TRY(hipMemcpy(h.data(), ctx->stamps, kStampWaves * 64, hipMemcpyDeviceToHost));
-    for (int k = 0; k < 8; ++k) out[k] = 0;
+    std::vector<unsigned long long> h(kStampWaves * kStampRec);
+    HIP_TRY(hipMemcpy(h.data(), ctx->stamps, kStampWaves * kStampRec * 8, hipMemcpyDeviceToHost));
+    for (size_t k = 0; k < kStampRec; ++k) out[k] = 0;
     for (size_t w = 0; w < kStampWaves; ++w)
-        for (int k = 0; k < 8; ++k) out[k] += h[w * 8 + k];
+        for (size_t k = 0; k < kStampRec; ++k) out[k] += h[w * kStampRec + k];
     return FIUNET_OK;
 }
-// the raw per-wave records ([kStampWaves][8] u64; record[6] != 0 where a wave wrote); returns the record count
+// the raw per-wave records ([kStampWaves][16] u64; record[8] != 0 where a wave wrote); returns the record count
 int fiunet_debug_stamp_records(fiunet_ctx* ctx, unsigned long long* out, size_t max_records)
 {
     HIP_TRY(hipDeviceSynchronize());
     const size_t n = std::min(max_records, kStampWaves);
-    HIP_TRY(hipMemcpy(out, ctx->stamps, n * 64, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(out, ctx->stamps, n * kStampRec * 8, hipMemcpyDeviceToHost));
     return (int)n;
 }
 #endif

@@ -130,7 +130,7 @@ def _pair_batches(n_pairs: int, batch: int):
         yield s, min(batch, n_pairs - s)
 
 
-def _forward_u8_chunk(model, a: torch.Tensor, b: torch.Tensor, batch: int) -> torch.Tensor:
+def _forward_u8_chunk(model, a: torch.Tensor, b: torch.Tensor, batch: int, out: torch.Tensor | None = None) -> torch.Tensor:
     """forward_u8 of one chunk of a sequence.  Below 1080p some layers of a forward have fewer workgroups
     than the chip has CUs and cut their K loop over several (split-K, fiunet.hip); how many depends on the
     batch (at 720p batches of fewer than five pairs still split the deepest level), so the fp32 summation
@@ -151,8 +151,13 @@ def _forward_u8_chunk(model, a: torch.Tensor, b: torch.Tensor, batch: int) -> to
         rep[0] = target - cnt
         a = torch.cat([a, a[-1:].repeat(*rep)])
         b = torch.cat([b, b[-1:].repeat(*rep)])
-        return model.forward_u8(a, b)[:cnt]
-    return model.forward_u8(a, b)
+        res = model.forward_u8(a, b)[:cnt]
+        if out is not None:
+            out.copy_(res)
+            return out
+        return res
+    # `out` (the video loops: every second frame of the interleaved result): the fused head stores each frame in place
+    return model.forward_u8(a, b, out=out)
 
 
 def sequence_pair_fn(model, batch: int = 8):
@@ -161,10 +166,12 @@ def sequence_pair_fn(model, batch: int = 8):
     frames are padded to `batch` exactly as `interpolate_sequence` pads its own (use the same `batch` for
     both and the sharded result equals the single-process one bit for bit at every frame size)."""
     @torch.no_grad()
-    def pair_fn(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
+    def pair_fn(a: torch.Tensor, b: torch.Tensor, out: torch.Tensor | None = None) -> torch.Tensor:
         if a.dim() == 3:
-            return _forward_u8_chunk(model, a.unsqueeze(1), b.unsqueeze(1), batch).squeeze(1)
-        return _forward_u8_chunk(model, a, b, batch)
+            return _forward_u8_chunk(model, a.unsqueeze(1), b.unsqueeze(1), batch,
+                                     None if out is None else out.unsqueeze(1)).squeeze(1)
+        return _forward_u8_chunk(model, a, b, batch, out)
+    pair_fn.accepts_out = True   # video.interpolate_video_sharded: the root's own middles go straight into the interleaved result
     return pair_fn
 
 
@@ -178,8 +185,8 @@ def interpolate_sequence(model, frames_u8: torch.Tensor, batch: int = 8) -> torc
     n = fr.shape[0]
     out = torch.empty((2 * n - 1,) + tuple(fr.shape[1:]), dtype=torch.uint8, device=fr.device)
     out[0::2] = fr
-    for s, cnt in _pair_batches(n - 1, batch):
-        out[2 * s + 1: 2 * (s + cnt): 2] = _forward_u8_chunk(model, fr[s:s + cnt], fr[s + 1:s + cnt + 1], batch)
+    for s, cnt in _pair_batches(n - 1, batch):   # each middle is written where it belongs (no temporary, no strided copy)
+        _forward_u8_chunk(model, fr[s:s + cnt], fr[s + 1:s + cnt + 1], batch, out=out[2 * s + 1: 2 * (s + cnt): 2])
     return out.squeeze(1) if squeeze else out
 
 

@@ -147,6 +147,16 @@ def exchange_halos(core1: torch.Tensor, core2: torch.Tensor, plan: List[Strip], 
     return band1, band2
 
 
+def _agree_or_raise(problem: Optional[str], device, group) -> None:
+    """Argument check that must fail on EVERY rank or on none: a rank that raised alone would leave its peers inside
+    receives that never complete (over RCCL a hang, not an error).  One all-reduce (MAX) of a flag - control plane, a few
+    bytes, before any point-to-point operation of the call - then the same exception everywhere."""
+    flag = torch.tensor([1 if problem else 0], dtype=torch.int32, device=device)
+    dist.all_reduce(flag, op=dist.ReduceOp.MAX, group=group)
+    if int(flag.item()):
+        raise ValueError(problem or "a peer rank rejected its arguments (see that rank's message)")
+
+
 def forward_tiled_halo_exchange(strip_fn: StripFn, frame1: Optional[torch.Tensor], frame2: Optional[torch.Tensor],
                                 shape, device, root: int = 0, halo: int = HALO, group=None,
                                 wire: torch.dtype = torch.float32, pre=None, post=None,
@@ -165,6 +175,19 @@ def forward_tiled_halo_exchange(strip_fn: StripFn, frame1: Optional[torch.Tensor
     plan = strip_plan(h, world, halo)
     mine = plan[rank]
     have = mine.core1 > mine.core0
+    # every buffer that goes on a link must have the size its peer posted: checked on all ranks before the first transfer
+    problem = None
+    if cores is not None:
+        want = (b, c, max(mine.core1 - mine.core0, 0), w)
+        for t in cores:
+            if tuple(t.shape) != want or t.dtype != wire:
+                problem = f"rank {rank}: core rows are {tuple(t.shape)} {t.dtype}, the plan says {want} {wire}"
+    elif rank == root:
+        for t in (frame1, frame2):
+            if t is None or tuple(t.shape) != (b, c, h, w) or t.dtype != wire:
+                problem = (f"root's frames are {None if t is None else (tuple(t.shape), t.dtype)}, "
+                           f"expected {(b, c, h, w)} in the wire dtype {wire}")
+    _agree_or_raise(problem, device, group)
     # 1. core rows: root -> ranks (no halo on these links)
     if cores is not None:
         c1, c2 = cores
@@ -221,11 +244,16 @@ def forward_tiled_distributed(strip_fn: StripFn, frame1: Optional[torch.Tensor],
     rank, world = dist.get_rank(group), dist.get_world_size(group)
     if wire not in (torch.float32, torch.uint8):
         raise ValueError("wire must be torch.float32 or torch.uint8")
-    if rank == root and (frame1.dtype != wire or frame2.dtype != wire):
-        raise ValueError(f"root's frames are {frame1.dtype} / {frame2.dtype}, wire is {wire}")
+    b, c, h, w = shape
+    problem = None
+    if rank == root:
+        for t in (frame1, frame2):
+            if t is None or tuple(t.shape) != (b, c, h, w) or t.dtype != wire:
+                problem = (f"root's frames are {None if t is None else (tuple(t.shape), t.dtype)}, "
+                           f"expected {(b, c, h, w)} in the wire dtype {wire}")
+    _agree_or_raise(problem, device, group)   # (every rank raises, none is left inside a receive)
     if wire == torch.uint8:
         strip_fn = u8_strip_fn(strip_fn, pre, post)
-    b, c, h, w = shape
     plan = strip_plan(h, world, halo)
     mine = plan[rank]
     # 1. input bands (+halo): root -> ranks

@@ -328,16 +328,21 @@ class FrameInterpolationUNet(nn.Module):
         return out
 
     @torch.no_grad()
-    def forward_u8(self, frame1: torch.Tensor, frame2: torch.Tensor) -> torch.Tensor:
+    def forward_u8(self, frame1: torch.Tensor, frame2: torch.Tensor, out: torch.Tensor | None = None) -> torch.Tensor:
         """uint8 [B,C,H,W] frames in -> uint8 interpolated frame, with the reference's
-        pre/post-processing (inference.py:31-35, :54-61) on device."""
+        pre/post-processing (inference.py:31-35, :54-61) on device.  `out`: write the result there instead of into a
+        new tensor - uint8, same shape and device, every image contiguous; the images may lie apart (the video loop
+        passes every second frame of its interleaved result, `fiunet_forward_u8_strided`)."""
         self._check_pair(frame1, frame2, (torch.uint8,))
         f1, f2 = frame1.contiguous(), frame2.contiguous()
         b, _, h, w = f1.shape
         prec = self._precision_code()
         ctx = self._context(f1.device)
         ws = self._workspace(ctx, f1.device, b, h, w, prec, u8=True)
-        out = torch.empty_like(f1)
+        if out is None:
+            out = torch.empty_like(f1)
+        elif out.dtype != torch.uint8 or out.shape != f1.shape or out.device != f1.device:
+            raise ValueError(f"out must be a uint8 {tuple(f1.shape)} tensor on {f1.device}")
         with torch.cuda.device(f1.device):
             ctx.forward_u8(f1, f2, out, prec, ws)
         return out

@@ -292,12 +292,15 @@ def interpolate_video_sharded(pair_fn: Callable[[torch.Tensor, torch.Tensor], to
                 src = frames[my_first + o:my_first + o + c + 1]
             else:
                 src = recv_ring[j % RING][:c + 1]
-            m = pair_fn(src[:c], src[1:c + 1])
             if is_root:
                 a = my_first + o
-                out[2 * a + 1:2 * (a + c):2] = m
+                dst = out[2 * a + 1:2 * (a + c):2]
+                if getattr(pair_fn, "accepts_out", False):   # (inference.sequence_pair_fn: written in place by the fused head)
+                    pair_fn(src[:c], src[1:c + 1], out=dst)
+                else:
+                    dst.copy_(pair_fn(src[:c], src[1:c + 1]))
             else:
-                mids[j] = m
+                mids[j] = pair_fn(src[:c], src[1:c + 1])
         pending += gather_step(j)
         mids.pop(j - 1, None)  # its send was issued one step ago (and record_stream-ed on the comm stream)
     st.finish(pending)

@@ -676,10 +676,16 @@ def main():
             fp32 = fp32_legs(dev)
         except Exception as e:  # an extra leg must never cost the headline line
             fp32 = {"error": f"{type(e).__name__}: {e}"}
+    small = None
+    if world == 1 and default_workload and not args.no_fp32:
+        try:
+            small = small_frames_leg(dev)
+        except Exception as e:  # an extra leg must never cost the headline line
+            small = {"error": f"{type(e).__name__}: {e}"}
     if world == 1 and not args.no_cpu_baseline:
         cpu_baseline, parity = cpu_legs(dev, args.precision)
     print(json.dumps(headline(args, world, elapsed, rows, nfw, default_workload, video_res, tile_res,
-                              cpu_baseline, parity, fp32, power, rgb, x2)))
+                              cpu_baseline, parity, fp32, power, rgb, x2, small)))
     if dist is not None:
         dist.destroy_process_group()
 
@@ -924,8 +930,76 @@ def fp32_legs(dev):
     return out
 
 
+def small_frames_leg(dev):
+    """north_star: "throughput on synthetic 256x256 and 1080p pairs ... as fraction of the roofline".  (a) `latency_256`:
+    ONE 256x256 pair - the only size the reference itself ever runs (model/inference.py:29,101-122 resize every input to
+    256x256 and forward one pair) - back to back, 20 warm-up + 200 timed forwards between HIP events on the launch stream,
+    in every precision, with the fraction of the MFMA peak the 79.9 GFLOP of a forward reach and the launch count (a
+    forward of this size is bounded by its ~17-30 dependent dispatches at ~4.5 us each as much as by arithmetic);
+    (b) `b16_256x256_bf16`: BASELINE configs[1]'s batch in the headline precision (SURVEY 8d config 2 protocol:
+    10 warm-up + 50 timed).  The fp32 / bf16x2 figures of configs[1] are in `fp32` and `fp32_contract_on_bf16_pipe`."""
+    out = {"workload": "ONE 256x256 synthetic frame pair per forward (the reference's own operating point), inputs resident, "
+                       "20 warm-up + 200 timed forwards back to back, HIP events",
+           "flops_per_forward": conv_flops(256, 256)}
+    gen = torch.Generator(device=dev).manual_seed(0)
+    f1 = torch.rand(1, 1, 256, 256, device=dev, generator=gen) * 2 - 1
+    f2 = torch.rand(1, 1, 256, 256, device=dev, generator=gen) * 2 - 1
+    for prec in ("bf16", "bf16x2", "fp32"):
+        m = make_bench_model(prec).to(dev).eval()
+        for _ in range(20):
+            m(f1, f2)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        torch.cuda.synchronize()
+        e0.record()
+        for _ in range(200):
+            m(f1, f2)
+        e1.record()
+        torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1) / 200
+        m._ctx.profile_enable(True)
+        for _ in range(3):
+            m(f1, f2)
+        _, rows = m._ctx.profile_read()
+        m._ctx.profile_enable(False)
+        mult = 3.0 if prec == "bf16x2" else 1.0
+        peak = PEAK_TFLOPS["fp32" if prec == "fp32" else "bf16"]
+        tf = conv_flops(256, 256) / (ms * 1e-3) / 1e12
+        out[prec] = {"ms_per_forward": round(ms, 4), "frames_per_s": round(1e3 / ms, 1), "algorithmic_tflops": round(tf, 1),
+                     "roofline": {"bound": "mfma", "achieved": round(tf * mult, 1), "peak": peak, "unit": "TFLOP/s",
+                                  "frac": round(tf * mult / peak, 4),
+                                  "note": "executed MFMA rate of the whole forward (bf16x2: 3 MFMAs per product)"},
+                     # conv launches + one finalize pass per K-split stage (the name says so); the event records between
+                     # stages are not dispatches
+                     "dispatches_per_forward": sum(1 + ("+splitk" in r[0]) for r in rows[1:]) + (0 if "fused" in rows[0][0] else 1),
+                     "k_split_stages": sum("+splitk" in r[0] for r in rows),
+                     "small_tile_stages": sum(",64,8,32," in r[0] for r in rows)}
+        del m
+    del f1, f2
+    m = make_bench_model("bf16").to(dev).eval()
+    gen = torch.Generator(device=dev).manual_seed(1)
+    f1 = torch.rand(16, 1, 256, 256, device=dev, generator=gen) * 2 - 1
+    f2 = torch.rand(16, 1, 256, 256, device=dev, generator=gen) * 2 - 1
+    for _ in range(10):
+        m(f1, f2)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize()
+    e0.record()
+    for _ in range(50):
+        m(f1, f2)
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / 50
+    fps = 16 / (ms * 1e-3)
+    tf = fps * conv_flops(256, 256) / 1e12
+    out["b16_256x256_bf16"] = {"value": round(fps, 1), "unit": "frames/s", "ms_per_step": round(ms, 4), "steps": 50, "warmup": 10,
+                               "dtype": "bf16", "workload": "batch=16 256x256 synthetic frame pairs (BASELINE configs[1]'s batch, headline precision)",
+                               "roofline": {"bound": "mfma", "achieved": round(tf, 1), "peak": PEAK_TFLOPS["bf16"], "unit": "TFLOP/s",
+                                            "frac": round(tf / PEAK_TFLOPS["bf16"], 4)}}
+    return out
+
+
 def headline(args, world, elapsed, rows, nfw, default_workload, video_res, tile_res, cpu_baseline, parity,
-             fp32=None, power=None, rgb=None, x2=None):
+             fp32=None, power=None, rgb=None, x2=None, small=None):
     b, h, w = args.batch, args.height, args.width
     fps = world * b * args.steps / elapsed
     ms_step = elapsed / args.steps * 1e3
@@ -990,6 +1064,8 @@ def headline(args, world, elapsed, rows, nfw, default_workload, video_res, tile_
         result["rgb_6to3"] = rgb
     if x2 is not None:
         result["fp32_contract_on_bf16_pipe"] = x2
+    if small is not None:
+        result["latency_256"] = small
     if power is not None:
         result["power"] = power   # socket power and the driver's sclk, as reported: NOT what the fractions below rest on
     # The clock the kernels run at is measured IN the kernel (a -DFIUNET_CLOCK diagnostic build: s_memtime / s_memrealtime
@@ -1014,6 +1090,12 @@ def headline(args, world, elapsed, rows, nfw, default_workload, video_res, tile_
             pass
     if video_res is not None:
         result["video_sharded"] = video_res
+        # config-4 efficiency at top level: end-to-end video rate / (n_gpus x this run's per-GPU headline rate)
+        if isinstance(video_res.get("interpolated_frames_per_s"), (int, float)) and fps > 0:
+            result["video_sharded_efficiency"] = round(video_res["interpolated_frames_per_s"] / fps, 4)
+            result["video_sharded_efficiency_note"] = ("video_sharded.interpolated_frames_per_s / value (value is already the "
+                                                       "whole-job rate over n_gpus): 1.0 = the end-to-end video loop, transfers "
+                                                       "included, runs at the rate of the bare forwards")
         if world > 1:   # what the communicator actually did, where a reader of the N > 1 line looks first
             result["rccl_ranks_seen"] = video_res.get("ranks")
             result["pairs_per_rank"] = video_res.get("pairs_per_rank")

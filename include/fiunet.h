@@ -21,7 +21,7 @@
 extern "C" {
 #endif
 
-#define FIUNET_ABI_VERSION 4   /* 4: fiunet_prepare_precision; fiunet_debug_read_activation takes the capacity of dst */
+#define FIUNET_ABI_VERSION 5   /* 4: fiunet_prepare_precision; fiunet_debug_read_activation takes the capacity of dst; 5: fiunet_forward_u8_strided */
 
 enum fiunet_status {
     FIUNET_OK = 0,
@@ -158,6 +158,13 @@ size_t fiunet_workspace_bytes_u8(const fiunet_ctx* ctx, int B, int H, int W, int
 int fiunet_forward_u8(fiunet_ctx* ctx, const uint8_t* frame1, const uint8_t* frame2, uint8_t* out,
                       int B, int H, int W, int precision, void* workspace, size_t workspace_bytes,
                       void* stream);
+/* The same with the B output images `out_image_stride` BYTES apart (0 = contiguous; >= frame_channels * H * W): the
+ * factor-2 video loop (the phantom `interpolate_video` of /root/reference/main.py:118-129) hands
+ * over every second frame of its interleaved result F0 M0 F1 M1 ..., so the fused head writes each interpolated frame
+ * where it belongs - no temporary, no strided copy afterwards.  Everything else as fiunet_forward_u8. */
+int fiunet_forward_u8_strided(fiunet_ctx* ctx, const uint8_t* frame1, const uint8_t* frame2, uint8_t* out,
+                              size_t out_image_stride, int B, int H, int W, int precision, void* workspace,
+                              size_t workspace_bytes, void* stream);
 
 /* Replaces preprocess_image's arithmetic (model/inference.py:31-35): out = 2*(in/255) - 1. */
 int fiunet_preprocess_u8(const uint8_t* in, float* out, size_t n, void* stream);

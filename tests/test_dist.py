@@ -212,6 +212,53 @@ def test_tiled_forward_world2(h, world):
     assert q.get(timeout=5) is True
 
 
+def _bad_args_worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        shape = (1, 1, 544, 20)
+        f = torch.rand(shape)
+        raised = []
+        # root holds fp32 frames, the call says uint8 on the wire; and a core of the wrong height on ONE rank:
+        # every rank must raise before any transfer (a lone raise would leave the peers inside receives)
+        for call in (
+            lambda: tiling.forward_tiled_halo_exchange(_box_strip_fn, f if rank == 0 else None, f if rank == 0 else None, shape,
+                                                       torch.device("cpu"), wire=torch.uint8, pre=_cpu_pre, post=_cpu_post),
+            lambda: tiling.forward_tiled_distributed(_box_strip_fn, f if rank == 0 else None, f if rank == 0 else None, shape,
+                                                     torch.device("cpu"), wire=torch.uint8, pre=_cpu_pre, post=_cpu_post),
+            lambda: tiling.forward_tiled_halo_exchange(
+                _box_strip_fn, None, None, shape, torch.device("cpu"),
+                cores=tuple(torch.rand(1, 1, tiling.strip_plan(544, world)[rank].core1 - tiling.strip_plan(544, world)[rank].core0
+                                       - (8 if rank == 1 else 0), 20) for _ in range(2))),
+        ):
+            try:
+                call()
+                raised.append(False)
+            except ValueError:
+                raised.append(True)
+        # and the group is still usable afterwards
+        out = tiling.forward_tiled_halo_exchange(_box_strip_fn, f if rank == 0 else None, f if rank == 0 else None, shape,
+                                                 torch.device("cpu"))
+        q.put((rank, raised, out is not None))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_tiled_forward_argument_errors_raise_on_every_rank():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_bad_args_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    got = sorted(q.get(timeout=5) for _ in range(2))
+    assert got == [(0, [True, True, True], True), (1, [True, True, True], False)], got
+
+
 # ---- weights: one broadcast of the flattened state --------------------------------------
 def _bcast_worker(rank, world, port, q):
     os.environ["MASTER_ADDR"] = "127.0.0.1"

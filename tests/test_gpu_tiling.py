@@ -71,7 +71,7 @@ def test_tiled_4k_four_bands_against_the_oracle(model, dev, seeded_sd):
     """BASELINE configs[4] without any process group: the 2160x3840 pair cut into the four bands of SURVEY 8d
     config 5 (origins 0/544/1088/1632) against the CPU ORACLE itself (not against the un-tiled HIP forward):
     fp32 within the 1e-3 contract and 1e-4 relative everywhere, with the rows either side of every cut
-    checked on their own; bf16 within the bf16 contract.  The oracle's 4K forward takes ~20-40 s of host time."""
+    checked on their own; bf16 within the bf16 contract; bf16x2 within the fp32 contract (1e-3), seams included.  The oracle's 4K forward takes ~20-40 s of host time."""
     f1, f2 = O.make_frames(9, 1, 2160, 3840)
     ref = O.unet_forward(seeded_sd, f1, f2)
     d1, d2 = f1.to(dev), f2.to(dev)
@@ -93,6 +93,15 @@ def test_tiled_4k_four_bands_against_the_oracle(model, dev, seeded_sd):
     # strided sample of the kept rows: what a 4-GPU run would gather (every 7th row, every 5th column)
     sm = (t16[..., ::7, ::5] - ref[..., ::7, ::5]).norm() / ref[..., ::7, ::5].norm()
     assert sm.item() <= 2e-2, sm.item()
+    # precision "bf16x2" (the fp32 contract on the bf16 pipe): the same four bands within the fp32 tolerance, seams included
+    model.precision = "bf16x2"
+    model.set_options()
+    tx2 = tiling.forward_tiled(model.forward_strip, d1, d2, 4).cpu()
+    dx = (tx2 - ref).abs()
+    assert dx.max().item() <= 1e-3, dx.max().item()
+    for cut in (544, 1088, 1632):
+        assert dx[..., cut - 8:cut + 8, :].max().item() <= 1e-3, (cut, dx[..., cut - 8:cut + 8, :].max().item())
+    model.precision = "fp32"
 
 
 def test_strip_uses_global_upsample_coordinates(model, dev):

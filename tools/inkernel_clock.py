@@ -22,7 +22,7 @@ L = _native.lib()
 L.fiunet_debug_stamp_layer.argtypes = [ctypes.c_void_p, ctypes.c_int]
 L.fiunet_debug_stamp_records.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t]
 NREC = 4 * 40000
-buf = np.zeros((NREC, 8), dtype=np.uint64)
+buf = np.zeros((NREC, 16), dtype=np.uint64)   # 128-B records; launches with more waves than NREC leave the rest unrecorded
 t0 = time.time()
 while time.time() - t0 < 2.5:      # >= 2 s of back-to-back forwards before the first stamp (the chip settles its clock)
     for _ in range(10): m(f1, f2)
@@ -40,7 +40,7 @@ for i in range(1, 18):
     m(f1, f2)
     n, rows = m._ctx.profile_read(); m._ctx.profile_enable(False)
     L.fiunet_debug_stamp_records(m._ctx._h, buf.ctypes.data_as(ctypes.c_void_p), NREC)
-    ok = (buf[:, 6] != 0) & (buf[:, 1] > 0)
+    ok = (buf[:, 8] != 0) & (buf[:, 1] > 0)
     ghz = buf[ok, 0].astype(np.float64) / buf[ok, 1].astype(np.float64) * 0.1
     name, ms, fl = rows[i]
     if not ok.any() or ms <= 0:

@@ -1,0 +1,11 @@
+set -o pipefail
+cd $GRAFT_REPO_ROOT && mkdir -p gpurun_out/r6b
+O=gpurun_out/r6b
+export FIUNET_LIB=ablibs/lib_stamp.so
+timeout -k 10 200 python tools/stamp_report.py 8 1080 1920 bf16 > $O/stamp_b8_1080p_bf16.txt 2>&1 || { tail $O/stamp_b8_1080p_bf16.txt; exit 1; }
+timeout -k 10 200 python tools/stamp_report.py 1 256 256 bf16 > $O/stamp_b1_256_bf16.txt 2>&1 || { tail $O/stamp_b1_256_bf16.txt; exit 1; }
+timeout -k 10 200 python tools/stamp_report.py 1 256 256 fp32 > $O/stamp_b1_256_fp32.txt 2>&1 || { tail $O/stamp_b1_256_fp32.txt; exit 1; }
+export FIUNET_LIB=ablibs/lib_stamp_prolog.so
+timeout -k 10 200 python tools/stamp_report.py 8 1080 1920 bf16 > $O/stamp_prolog_b8_1080p_bf16.txt 2>&1 || { tail $O/stamp_prolog_b8_1080p_bf16.txt; exit 1; }
+timeout -k 10 200 python tools/stamp_report.py 1 256 256 bf16 > $O/stamp_prolog_b1_256_bf16.txt 2>&1 || { tail $O/stamp_prolog_b1_256_bf16.txt; exit 1; }
+cat $O/stamp_prolog_b8_1080p_bf16.txt $O/stamp_prolog_b1_256_bf16.txt
