@@ -104,9 +104,9 @@ struct ConvArgs {
                               // with lane groups 0, 1, 2 <-> dy = 0, 2, 1; zero for dx = 3; k = 24 (lane group 3) holds
                               // the BatchNorm shift (its operand is 1.0); packed row R <-> cout bf16_row_to_cout(R)
     float dither;             // bf16 stem only: amplitude of the ordered input dither (stem_dither), 0 = off
-    // EPI_SPLITK: the K loop (planes) is cut into `ksplit` slices handled by different workgroups;
-    // slice s stores its raw fp32 partial sums to kslab[s][B*H*W][Cout]; splitk_finalize_kernel adds
-    // the slices in order (deterministic) and applies scale/shift/ReLU.
+    // EPI_SPLITK: the K loop (planes) is cut into `ksplit` slices handled by different workgroups; slice s stores its
+    // raw fp32 partial sums to kslab[s][tile][wave][fragment][lane]; splitk_finalize_tile_kernel adds the slices in
+    // index order (deterministic) on top of the BatchNorm shift and runs the epilogue.
     int ksplit;
     int pair;            // host side only: 8-wave tile-pair kernel where it applies (FIUNET_OPT_PAIR_TILES)
     int force_tile;      // host side only (diagnostic, fiunet_debug_force_cfg): 0 = choose, 1 = the big tile, 2 = the small one
@@ -451,7 +451,8 @@ __device__ __forceinline__ void mma_chunk<float>(f32x4& acc, const uint4& wa, co
 }
 
 enum Epilogue { EPI_PLAIN = 0, EPI_HEAD = 1 /* 1x1 head, 1 class */, EPI_POOL = 2, EPI_HEAD3 = 3 /* 3 classes */,
-                EPI_SPLITK = 4 /* raw fp32 partial sums of a K slice -> slab (small problems) */ };
+                EPI_SPLITK = 4 /* raw fp32 partial sums of a K slice -> slab (small problems); splitk_finalize_tile_kernel reduces */ };
+constexpr bool epi_is_splitk(int epi) { return epi == EPI_SPLITK; }
 
 // value of the neighbouring lane (lane ^ 1) through DPP quad_perm [1,0,3,2]: no LDS crossbar
 __device__ __forceinline__ unsigned dpp_swap_pairs(unsigned v)
@@ -560,7 +561,7 @@ __device__ __forceinline__ void conv_acc_init(const ConvArgs& a, f32x4 (&acc)[4]
 #pragma unroll
     for (int m = 0; m < 4; ++m) {
         f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
-        if constexpr (EPI != EPI_SPLITK) {  // K slices start from zero; splitk_finalize_kernel adds the shift
+        if constexpr (!epi_is_splitk(EPI)) {  // K slices start from zero; the reduction adds the shift
             const float4 sh = *reinterpret_cast<const float4*>(a.shift + ct * BN + wc * 64 + conv_cout_ofs<T>(m, lc));
             v = f32x4{sh.x, sh.y, sh.z, sh.w};
         }
@@ -595,11 +596,11 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x4 (&acc)[4]
     const int aH = a.H, aW = a.W;
     constexpr bool PERM = sizeof(T) == 2;
     const int wbase_c = ct * BN + wc * 64;  // first cout of this wave
-    if constexpr (EPI == EPI_SPLITK) {
+    if constexpr (epi_is_splitk(EPI)) {
         // raw fp32 partial sums of this K slice, in FRAGMENT order: slab[split][tile][wave][m * NF + n][lane] as float4,
         // so every store instruction of a wave writes 1 KiB contiguous (round 6; the pixel-major slab of rounds 1-5 was
         // written 16 B at a time with a stride of Cout floats: 29 % of a K-split kernel's wave time was this epilogue,
-        // gpurun_out/r6b/stamp_b1_256_bf16.txt).  splitk_finalize_tile_kernel reads it back in the same order.
+        // profiles/r06_stamp_phases_b1_256_before_small_tiles.txt).  splitk_finalize_tile_kernel reads it back in the same order.
         const int tile = (((b * a.tilesY) + y0 / TH) * a.tilesX + x0 / TW) * a.nct + ct;
         const int ntile = a.B * a.tilesY * a.tilesX * a.nct;
         const int wave = wp * (BN / 64) + wc;
@@ -929,7 +930,7 @@ __global__ __launch_bounds__(256, conv_occupancy(BN, TH, TW, ConvTile<BN, TH, TW
         const int q = nblk >> 3, r = nblk & 7, xcd = bid & 7;
         lid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
     }
-    const int ksplit = EPI == EPI_SPLITK ? a.ksplit : 1;
+    const int ksplit = epi_is_splitk(EPI) ? a.ksplit : 1;
     const int split = lid % ksplit;
     lid /= ksplit;
     const int ct = lid % a.nct;
@@ -1059,7 +1060,7 @@ __global__ __launch_bounds__(256, conv_occupancy(BN, TH, TW, ConvTile<BN, TH, TW
     // reads per step): bf16 32-wide tiles.  The fp32 instantiations (4 MFMAs per fragment pair keep
     // more operands in flight) and the 16-wide tiles have no registers to spare for the extra row
     // and re-read every row for every tap instead; same tap order, same sums.
-    constexpr bool ROLL = sizeof(T) == 2 && FR == 2 && (EPI != EPI_SPLITK || NF == 4);
+    constexpr bool ROLL = sizeof(T) == 2 && FR == 2 && (!epi_is_splitk(EPI) || NF == 4);
     constexpr int NPW = (NPIECE + 3) / 4;
     unsigned in_off[HOIST ? NPW : 1];
     const unsigned plane_bytes = (unsigned)(aH * aW) * 64u;
@@ -1530,10 +1531,12 @@ __global__ __launch_bounds__(256, conv_occupancy(BN, TH, TW, ConvTile<BN, TH, TW
     // the first in-tile gather of every kernel that fetches it by DMA - the kernel as it would run if a cross-tile prefetch
     // had delivered both for free (the upper bound of lever (a)); -DFIUNET_DIAG_NO_WSTREAM drops the whole weight stream - the
     // upper bound of weights held in LDS for the kernel's lifetime (lever (b))
+    // (staging area of an upsampled first plane - a K slice may start in the upsampled half: the slot no prologue request
+    // went to, i.e. the last one)
 #ifdef FIUNET_DIAG_FREE_PROLOGUE
-    if constexpr (STEM || MODE == SRC_CONCAT_UP) gather_plane(pbeg, 1, true);
+    if constexpr (STEM || MODE == SRC_CONCAT_UP) gather_plane(pbeg, NSLOT - 1, true);
 #else
-    gather_plane(pbeg, 1, true);
+    gather_plane(pbeg, NSLOT - 1, true);
 #endif
     PSTAMP(13);
     lds_dma_wait_all();
@@ -1701,6 +1704,12 @@ __global__ __launch_bounds__(256, conv_occupancy(BN, TH, TW, ConvTile<BN, TH, TW
 // two-piece split of precision "bf16x2", all from one code path (rounds 1-5: a pixel-major slab, an element-wise
 // finalize kernel and a separate max-pool launch).  The slab is read in the fragment order the conv wrote it in
 // (conv_epilogue, EPI_SPLITK): 1 KiB contiguous per load instruction.
+// Tried instead and NOT shipped (round 6): the reduction inside the conv kernel by the last workgroup of a tile to
+// arrive (arrival counter, no waiting, one dispatch less per cut stage).  With agent-scope fences around the slab
+// accesses (`buffer_wbl2` + `buffer_inv`: each workgroup writes back / drops its XCD's whole L2) it is correct - all
+// GPU tests, 5 400 forwards bit-identical - and 1.2-1.6x SLOWER end to end (ONE 256x256 pair: bf16 0.295 -> 0.486 ms,
+// fp32 0.913 -> 1.134); with write-through (sc0 sc1) stores instead of the release fence it is fast and WRONG (stale
+// slices across XCDs: golden 135x240 fails).  The dispatch boundary is the cheapest coherence point this chip offers.
 template <typename T, int BN, int TH, int TW, int EPI, bool X2>
 __global__ __launch_bounds__(256) void splitk_finalize_tile_kernel(const ConvArgs a)
 {
@@ -1724,22 +1733,23 @@ __global__ __launch_bounds__(256) void splitk_finalize_tile_kernel(const ConvArg
         for (int n = 0; n < NF; ++n) acc[m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
     const float4* p = reinterpret_cast<const float4*>(a.kslab) + (((size_t)tile * 4 + wave) * (4 * NF)) * 64 + lane;
     const size_t slice = (size_t)ntile * 4 * (4 * NF) * 64;
-    // slices in chunks of four: the 4 x NF loads of a cout tile are independent and issued together (the pass is a chain
-    // of memory round trips, not bandwidth: one slice per trip took ~0.5 us per slice), the additions stay in slice order
+    // slices in chunks: the CH x NF loads of a cout tile are independent and issued together (the pass is a chain of
+    // memory round trips, not bandwidth: one slice per trip took ~0.5 us per slice), the additions stay in slice order
     const int ks = a.ksplit;
 #pragma unroll
     for (int m = 0; m < 4; ++m) {
         const float4* pm = p + (size_t)m * NF * 64;
-        for (int s0 = 0; s0 < ks; s0 += 4, pm += 4 * slice) {
-            float4 q[4][NF];
+        constexpr int CH = NF == 8 ? 2 : 4;   // (128 accumulator registers leave room for two slices in flight, 64 for four)
+        for (int s0 = 0; s0 < ks; s0 += CH, pm += CH * slice) {
+            float4 q[CH][NF];
 #pragma unroll
-            for (int j = 0; j < 4; ++j)
+            for (int j = 0; j < CH; ++j)
                 if (s0 + j < ks) {
 #pragma unroll
                     for (int n = 0; n < NF; ++n) q[j][n] = pm[j * slice + n * 64];
                 }
 #pragma unroll
-            for (int j = 0; j < 4; ++j)
+            for (int j = 0; j < CH; ++j)
                 if (s0 + j < ks) {
 #pragma unroll
                     for (int n = 0; n < NF; ++n) {

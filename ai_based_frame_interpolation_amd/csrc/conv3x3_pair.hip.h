@@ -54,7 +54,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_pair_kernel(const ConvArgs a)
     static_assert(NF == 8 || NF == 4, "wave tile must be 64 couts x 128 or 64 pixels");
     static_assert(TH == ROWS_W * WAVES_P && ROWS_W * FR == NF, "tile does not split over the waves");
     static_assert(EPI != EPI_POOL || ROWS_W % 2 == 0, "pooled epilogue: a wave owns whole row pairs");
-    static_assert(EPI != EPI_SPLITK, "small problems stay on conv3x3_mfma_kernel");
+    static_assert(!epi_is_splitk(EPI), "small problems stay on conv3x3_mfma_kernel");
     constexpr int HNC = EPI == EPI_HEAD ? 1 : (EPI == EPI_HEAD3 ? 3 : 0);
     static_assert(HNC == 0 || BN == 64, "fused head needs all 64 couts in one wave");
 

@@ -293,7 +293,7 @@ int launch_conv_cfg(ConvArgs a, hipStream_t s)
     a.tilesX = (a.W + TW - 1) / TW;
     a.tilesY = (a.H + TH - 1) / TH;
     a.nct = a.Cout / BN;
-    const long long nblk = (long long)a.B * a.tilesX * a.tilesY * a.nct * (EPI == EPI_SPLITK ? a.ksplit : 1);
+    const long long nblk = (long long)a.B * a.tilesX * a.tilesY * a.nct * (epi_is_splitk(EPI) ? a.ksplit : 1);
     if (nblk <= 0 || nblk > 0x7fffffffLL) return fail(FIUNET_ERR_INVALID_ARG, "conv grid too large");
     // > 64 KiB of dynamic LDS needs the opt-in attribute, once per kernel and device
     static std::atomic<bool> lds_attr_set[64];  // a duplicate hipFuncSetAttribute is harmless
@@ -392,54 +392,73 @@ inline long long tile_blocks(const TileShape& t, int B, int H, int W, int Cout)
     return (long long)B * ((W + t.TW - 1) / t.TW) * ((H + t.TH - 1) / t.TH) * (Cout / t.BN);
 }
 
-// Estimated duration (ns) of one conv launch (+ its finalize pass when the K loop is cut).  Constants from the per-layer
-// sweep of tools/cfg_sweep.py on MI355X (profiles/r06_cfg_sweep_*.txt): a dependent dispatch costs ~4.5 us whatever it
-// does; a workgroup's prologue + epilogue ~2.5 us; a step (one plane x kx, three taps) is MFMA time at one wave per SIMD -
-// bf16 0.73 us for a 64 x 128 wave tile, half of it for 64 x 64, fp32 8x that - plus ~0.25 us of waits and barriers, and
-// co-resident workgroups share the SIMD's MFMA pipe.
-inline double conv_cost_ns(bool fp32, bool small, long long nblk, int nplanes, int ksplit, bool x2)
+// K cut of a small problem (tools/cfg_sweep.py on MI355X, ONE 256x256 pair and B = 16 / 1080p B = 1 as cross-checks:
+// profiles/r06_cfg_sweep_*.txt).  What the sweep shows:
+//  * the small tile beats the big one on every layer of a problem the big tile cannot fill the chip with (12-35 %);
+//  * bf16: a lone workgroup's step (48 MFMAs, a barrier, the waits) takes ~0.6 us whatever is done about the weight
+//    stream (a 4-deep ring changed nothing), a dependent dispatch ~4.5 us, and the slab of a cut costs its bytes twice
+//    (k slices of the padded fp32 output written, then read back through the Infinity Cache at ~2.5-4.5 TB/s): cutting
+//    pays from 8 planes (24 serial steps) on, best at 2-4 planes per slice - k = 4 for 8 planes, 8 beyond;
+//  * fp32: a step is MFMA time (~3 us per 64 x 64 wave tile), so what counts is one workgroup on every CU: k = 256 /
+//    workgroups (a second workgroup per CU shares the same MFMA pipes: no gain, twice the slab);
+//  * never more workgroups than 512 (bf16) / 256 (fp32) in total, never a slab beyond kSlabBytes.
+inline int pow2_floor(long long v) { int k = 1; while (2LL * k <= v) k *= 2; return k; }
+
+inline int small_ksplit(bool fp32, long long nblk, int nplanes, bool concat)
 {
-    const double t_launch = 4500.0, t_fix = 2500.0, t_ovh = 250.0;
-    const int occ = small ? 3 : 2;
-    const double mfma_step = (fp32 ? 5850.0 : 730.0) * (small ? 0.5 : 1.0);
-    const long long nwg = nblk * ksplit;
-    const int steps = (nplanes + ksplit - 1) / ksplit * 3;
-    const long long slots = 256LL * occ;
-    const long long rounds = (nwg + slots - 1) / slots;
-    // workgroups sharing a CU in a full round share its MFMA pipes; a lone partial round runs at its own occupancy
-    const double share = rounds > 1 ? (double)occ : (double)std::max<long long>(1, (nwg + 255) / 256);
-    double ns = t_launch + rounds * (t_fix + steps * (mfma_step * share + t_ovh));
-    if (ksplit > 1) ns += t_launch + 1200.0 + 120.0 * ksplit * (x2 ? 1.5 : 1.0);
-    return ns;
+    int k;
+    if (nblk >= 256) return 1;   // one workgroup per CU already: a cut only adds the slab (B = 16 256x256, level 4: 39.3 -> 42.9 us)
+    if (fp32) k = pow2_floor(std::max<long long>(1, 256 / std::max<long long>(nblk, 1)));
+    else {
+        k = nplanes < 8 ? 1 : (nplanes < 16 ? 4 : 8);
+        k = std::min(k, pow2_floor(std::max<long long>(1, 512 / std::max<long long>(nblk, 1))));
+    }
+    (void)concat;
+    k = std::min(k, pow2_floor(nplanes));
+    while (k > 1 && (size_t)k * nblk * kSmallTile.BN * kSmallTile.TH * kSmallTile.TW * 4 > kSlabBytes) k /= 2;
+    return k;
 }
 
 // `splittable`: plain / pooled epilogue with a slab to write to (never the fused stem or the fused head).
-// force_small: -1 = choose, 0 / 1 = debug override; force_ksplit: 0 = choose, k >= 1 = debug override.
+// force_small: -1 = choose, 0 / 1 = debug override; force_ksplit: 0 = choose, k >= 1 = debug override (powers of two).
 inline ConvCfg choose_conv_cfg(bool fp32, bool x2, int B, int H, int W, int Cin, int Cout, bool splittable,
-                               int force_small = -1, int force_ksplit = 0)
+                               int force_small = -1, int force_ksplit = 0, bool concat = false)
 {
     const int PL = fp32 ? 16 : 32;
     const int nplanes = Cin / PL * (x2 ? 3 : 1);
     const TileShape big = big_tile(H, W, Cout);
     const long long nblk_big = tile_blocks(big, B, H, W, Cout), nblk_small = tile_blocks(kSmallTile, B, H, W, Cout);
-    ConvCfg best{false, 1};
-    if (nblk_big >= 256 && force_small < 0 && force_ksplit <= 0) return best;   // the chip is full: the tuned tile, whole K loop
+    // the chip is full with the tuned tile: whole K loop, nothing to choose
+    if (nblk_big >= 256 && force_small < 0 && force_ksplit <= 0) return ConvCfg{false, 1};
     const bool may_split = splittable && nblk_big < (nblk_big / B < 64 ? 256 : 128);
-    double best_ns = 1e30;
-    for (int small = 0; small < 2; ++small) {
-        if (force_small >= 0 && small != force_small) continue;
-        const TileShape& t = small ? kSmallTile : big;
-        const long long nblk = small ? nblk_small : nblk_big;
-        for (int k = 1; k <= 32; k *= 2) {
-            if (force_ksplit > 0 ? k != force_ksplit : (k > 1 && !may_split)) continue;
-            if (k > 1 && (!splittable || k > nplanes)) continue;
-            // slab: ksplit slices of the PADDED output in fp32
-            if (k > 1 && (size_t)k * nblk * t.BN * t.TH * t.TW * 4 > kSlabBytes) continue;
-            const double ns = conv_cost_ns(fp32, small != 0, nblk, nplanes, k, x2);
-            if (ns < best_ns) { best_ns = ns; best = ConvCfg{small != 0, k}; }
-        }
+    auto big_ksplit = [&]() {   // the rule of rounds 1-5 for the tuned tiles (powers of two)
+        int k = (int)std::min<long long>(std::min(nplanes / 2, 16), (256 + nblk_big - 1) / nblk_big);
+        k = k > 1 ? pow2_floor(k) : 1;
+        while (k > 1 && (size_t)k * nblk_big * big.BN * big.TH * big.TW * 4 > kSlabBytes) k /= 2;
+        return k;
+    };
+    bool small = force_small >= 0 ? force_small != 0 : true;
+    if (force_small < 0 && fp32) {
+        // fp32 is MFMA-bound per SIMD: where the 8x32 tile pads a narrow level (16 columns: half of every tile is
+        // padding) AND the batch already fills the chip, the tuned 16x16 tile with its K cut does half the MFMAs
+        // (B = 16 256x256, level 4: 64 tuned workgroups x 4 slices x 24 steps against 256 small ones x 96 steps)
+        auto mfma_ns = [&](long long nblk, int k, double step_ns) {
+            const long long nwg = nblk * k;
+            return (double)((nwg + 255) / 256) * ((nplanes + k - 1) / k * 3) * step_ns + (k > 1 ? 8000.0 : 0.0);
+        };
+        const int ks = may_split ? small_ksplit(true, nblk_small, nplanes, concat) : 1, kb = may_split ? big_ksplit() : 1;
+        small = mfma_ns(nblk_small, ks, 2950.0) <= mfma_ns(nblk_big, kb, 5900.0);
     }
-    return best;
+    const TileShape& t = small ? kSmallTile : big;
+    const long long nblk = small ? nblk_small : nblk_big;
+    int k = 1;
+    if (force_ksplit > 0) {
+        k = splittable ? std::min(pow2_floor(force_ksplit), pow2_floor(nplanes)) : 1;
+        while (k > 1 && (size_t)k * nblk * t.BN * t.TH * t.TW * 4 > kSlabBytes) k /= 2;
+    } else if (may_split) {
+        k = small ? small_ksplit(fp32, nblk, nplanes, concat) : big_ksplit();
+    }
+    return ConvCfg{small, k};
 }
 
 // pair kernel: direct sources, plain / pooled epilogue, enough tile pairs to fill the 256 CUs
@@ -451,7 +470,6 @@ constexpr bool pair_capable() { return MODE == SRC_DIRECT && (EPI == EPI_PLAIN |
 template <typename T, int BN, int TH, int TW, int MODE, int EPI>
 int launch_conv_maybe_split(ConvArgs a, hipStream_t s, int ksplit)
 {
-    constexpr bool X2 = src_is_x2(MODE);   // precision bf16x2: two-piece operands and output, 3 virtual planes per plane
     if constexpr (!src_is_stem(MODE) && (EPI == EPI_PLAIN || EPI == EPI_POOL)) {
         if (ksplit > 1 && a.kslab && a.dst) {
             ConvArgs k = a;
@@ -462,7 +480,7 @@ int launch_conv_maybe_split(ConvArgs a, hipStream_t s, int ksplit)
             k.tilesY = (a.H + TH - 1) / TH;
             k.nct = a.Cout / BN;
             const long long ntile = (long long)a.B * k.tilesX * k.tilesY * k.nct;
-            hipLaunchKernelGGL((splitk_finalize_tile_kernel<T, BN, TH, TW, EPI, X2>), dim3((unsigned)ntile), dim3(256), 0, s, k);
+            hipLaunchKernelGGL((splitk_finalize_tile_kernel<T, BN, TH, TW, EPI, src_is_x2(MODE)>), dim3((unsigned)ntile), dim3(256), 0, s, k);
             HIP_TRY(hipGetLastError());
             if (g_name_out) *g_name_out += "+splitk" + std::to_string(ksplit);
             return FIUNET_OK;

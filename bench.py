@@ -935,7 +935,7 @@ def small_frames_leg(dev):
     ONE 256x256 pair - the only size the reference itself ever runs (model/inference.py:29,101-122 resize every input to
     256x256 and forward one pair) - back to back, 20 warm-up + 200 timed forwards between HIP events on the launch stream,
     in every precision, with the fraction of the MFMA peak the 79.9 GFLOP of a forward reach and the launch count (a
-    forward of this size is bounded by its ~17-30 dependent dispatches at ~4.5 us each as much as by arithmetic);
+    forward of this size is bounded by its ~27-32 dependent dispatches at ~4.5 us each as much as by arithmetic);
     (b) `b16_256x256_bf16`: BASELINE configs[1]'s batch in the headline precision (SURVEY 8d config 2 protocol:
     10 warm-up + 50 timed).  The fp32 / bf16x2 figures of configs[1] are in `fp32` and `fp32_contract_on_bf16_pipe`."""
     out = {"workload": "ONE 256x256 synthetic frame pair per forward (the reference's own operating point), inputs resident, "
@@ -968,9 +968,10 @@ def small_frames_leg(dev):
                      "roofline": {"bound": "mfma", "achieved": round(tf * mult, 1), "peak": peak, "unit": "TFLOP/s",
                                   "frac": round(tf * mult / peak, 4),
                                   "note": "executed MFMA rate of the whole forward (bf16x2: 3 MFMAs per product)"},
-                     # conv launches + one finalize pass per K-split stage (the name says so); the event records between
-                     # stages are not dispatches
-                     "dispatches_per_forward": sum(1 + ("+splitk" in r[0]) for r in rows[1:]) + (0 if "fused" in rows[0][0] else 1),
+                     # 17 conv launches + one reduce pass per K-cut stage (it also pools), the stem where it is not fused,
+                     # bf16x2's four upsample launches
+                     "dispatches_per_forward": 17 + sum("+splitk" in r[0] for r in rows) + (0 if "fused" in rows[0][0] else 1)
+                                               + (4 if prec == "bf16x2" else 0),
                      "k_split_stages": sum("+splitk" in r[0] for r in rows),
                      "small_tile_stages": sum(",64,8,32," in r[0] for r in rows)}
         del m

@@ -108,7 +108,8 @@ size_t fiunet_workspace_bytes(const fiunet_ctx* ctx, int B, int H, int W, int pr
 
 /* Smallest batch B (1..64; 65 = none) at which NO layer of a forward of H x W frames cuts its K loop over several
  * workgroups (see "Reproducibility" below): batches of at least that many pairs give every pair the same bits whatever
- * the batch.  1 from 1080p up, 5 at 720p, > 8 for the reference's own 256x256.  Needs loaded weights (it walks the
+ * the batch.  1 from 1080p up; at 720p 3 in fp32 and 2 in bf16 / bf16x2 (round 6 rule; 5 until round 5); > 8 for the
+ * reference's own 256x256.  The value holds for the context's current options, default tile choice included.  Needs loaded weights (it walks the
  * architecture); 0 on bad arguments.  Used by the video loops to pad a ragged last chunk no further than necessary.
  * The reference has no counterpart (aten's conv results do depend on the batch in the last bit). */
 int fiunet_min_unsplit_batch(const fiunet_ctx* ctx, int H, int W, int precision);
@@ -120,7 +121,7 @@ int fiunet_min_unsplit_batch(const fiunet_ctx* ctx, int H, int W, int precision)
  * workspace: device scratch of at least fiunet_workspace_bytes(...), 256-B aligned.
  * Reproducibility: a call is deterministic (no atomics; fixed summation order).  For frames of >= 1080p the
  * result of a pair does not depend on the batch it is part of or on its position (bit for bit); for smaller
- * frames that holds among batches of at least fiunet_min_unsplit_batch(ctx, H, W, precision) pairs (5 at 720p).
+ * frames that holds among batches of at least fiunet_min_unsplit_batch(ctx, H, W, precision) pairs (2 at 720p, bf16).
  * Below that, layers with fewer workgroups than the chip has CUs cut their K loop over several workgroups, and
  * how many depends on B, so the fp32 summation order of a pair - hence its last bit - may differ between batch
  * sizes (1.8e-5 in fp32 on O(1) outputs, bf16 ulp flips; the same holds for a short band of

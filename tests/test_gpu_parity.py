@@ -429,27 +429,30 @@ def test_sequence_result_does_not_depend_on_its_length_at_small_frames(model, de
 
 
 def test_ragged_chunks_are_padded_no_further_than_the_split_rule_needs(model, dev):
-    """`fiunet_min_unsplit_batch` is the library's own K-split rule: 1 from 1080p up (no layer ever splits), 5 at
-    720p (its deepest level has 60 workgroups per image: cut while the batch has fewer than 256), more than a batch at
-    the reference's 256x256.  A one-pair 720p clip is therefore computed as a batch of 5, not of 8 - and still equals
-    the pair computed inside a full batch."""
+    """`fiunet_min_unsplit_batch` is the library's own K-split rule: 1 from 1080p up (no layer ever splits); at 720p the
+    deepest level (45x80) is cut for a lone bf16 pair (round 6 rule: 144 small-tile workgroups per image, two K
+    slices) and for one or two fp32 pairs (MFMA-bound: the tuned 16x16 tile, which does not pad that level, with 4 / 2
+    slices beats 144 un-cut small workgroups); more than a batch at the reference's 256x256.  A one-pair 720p clip is therefore computed as a batch of `bmin`, not of 8 - and still equals the pair
+    computed inside a full batch."""
+    want_720 = {"fp32": 3, "bf16": 2, "bf16x2": 2}
     for prec in ("fp32", "bf16", "bf16x2"):
         model.precision = prec
         assert model.batch_invariant_from(1080, 1920) == 1
-        assert model.batch_invariant_from(720, 1280) == 5
+        assert model.batch_invariant_from(720, 1280) == want_720[prec], (prec, model.batch_invariant_from(720, 1280))
         assert model.batch_invariant_from(256, 256) > 8
     model.precision = "bf16"
+    bmin = model.batch_invariant_from(720, 1280)
     fr = S.moving_frames(0, 9, 720, 1280, device=dev, seed=4)
     calls = []
     orig = model.forward_u8
     model.forward_u8 = lambda a, b, out=None: (calls.append(a.shape[0]), orig(a, b, out=out))[1]
     try:
         full = P.interpolate_sequence(model, fr, batch=8)         # 8 pairs: one full batch
-        one = P.interpolate_sequence(model, fr[:2], batch=8)      # 1 pair -> padded to 5
+        one = P.interpolate_sequence(model, fr[:2], batch=8)      # 1 pair -> padded to bmin
         three = P.interpolate_sequence(model, fr[:7], batch=8)    # 6 pairs -> as they are
     finally:
         del model.forward_u8
-    assert calls == [8, 5, 6], calls
+    assert calls == [8, bmin, 6], calls
     assert torch.equal(one, full[:3]) and torch.equal(three, full[:13])
     model.precision = "fp32"
 
