@@ -167,6 +167,14 @@ class Context:
     def set_options(self, flags: int):
         check(lib().fiunet_set_options(self._h, flags), "fiunet_set_options")
 
+    def force_cfg(self, layer: int, tile: int = 0, ksplit: int = 0) -> None:
+        """Diagnostic (tests, tools/cfg_sweep.py; not part of the ABI): override the launch configuration of conv
+        `layer` (1..17; < 0 clears all) - tile 0 = choose, 1 = the tuned tile, 2 = the small tile, 3 = the in-workgroup
+        K cut where the launch has its form; ksplit 0 = choose, k = cut the K loop k ways where the launch can be cut."""
+        fn = lib().fiunet_debug_force_cfg
+        fn.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int]
+        check(fn(self._h, layer, tile, ksplit), "fiunet_debug_force_cfg")
+
     def load_state_dict(self, sd) -> None:
         names, ptrs, numels, keep = [], [], [], []
         for k, v in sd.items():

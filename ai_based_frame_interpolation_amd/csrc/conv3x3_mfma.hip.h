@@ -109,7 +109,7 @@ struct ConvArgs {
     // index order (deterministic) on top of the BatchNorm shift and runs the epilogue.
     int ksplit;
     int pair;            // host side only: 8-wave tile-pair kernel where it applies (FIUNET_OPT_PAIR_TILES)
-    int force_tile;      // host side only (diagnostic, fiunet_debug_force_cfg): 0 = choose, 1 = the big tile, 2 = the small one
+    int force_tile;      // host side only (diagnostic, fiunet_debug_force_cfg): 0 = choose, 1 = the big tile, 2 = the small one, 3 = conv3x3_kwave_kernel
     int force_ksplit;    // host side only (diagnostic): 0 = choose, k >= 1 = cut the K loop k ways
     float* kslab;
     unsigned long long* stamp;  // diagnostic builds (-DFIUNET_STAMP / -DFIUNET_CLOCK) only: one 128-B record (16 cycle sums) per wave
@@ -1698,7 +1698,7 @@ __global__ __launch_bounds__(256, conv_occupancy(BN, TH, TW, ConvTile<BN, TH, TW
 }
 
 // Second pass of a K-split conv (small problems: fewer workgroups than the chip has CUs, e.g. the deep levels of the ONE
-// 256x256 pair the reference runs, /root/reference/model/inference.py:29): one workgroup per (tile, cout tile) adds the
+// 256x256 pair the reference runs, /root/reference/model/inference.py:29): one wave per (tile, cout tile, conv wave) adds the
 // `ksplit` fp32 partial-sum slices in index order - deterministic, no atomics - on top of the BatchNorm shift, and then
 // runs the conv kernel's OWN epilogue on the sums: ReLU, the blocked store, the fused MaxPool2d(2) copy (EPI_POOL) and the
 // two-piece split of precision "bf16x2", all from one code path (rounds 1-5: a pixel-major slab, an element-wise
@@ -1710,19 +1710,21 @@ __global__ __launch_bounds__(256, conv_occupancy(BN, TH, TW, ConvTile<BN, TH, TW
 // GPU tests, 5 400 forwards bit-identical - and 1.2-1.6x SLOWER end to end (ONE 256x256 pair: bf16 0.295 -> 0.486 ms,
 // fp32 0.913 -> 1.134); with write-through (sc0 sc1) stores instead of the release fence it is fast and WRONG (stale
 // slices across XCDs: golden 135x240 fails).  The dispatch boundary is the cheapest coherence point this chip offers.
+// One 64-thread workgroup per (tile, conv wave): the pass is bound by how many CUs pull slab bytes at once (a deep fp32
+// level is 16 tiles x 16 slices x 64 KiB), not by arithmetic, and nothing in the epilogue crosses a wave.
 template <typename T, int BN, int TH, int TW, int EPI, bool X2>
-__global__ __launch_bounds__(256) void splitk_finalize_tile_kernel(const ConvArgs a)
+__global__ __launch_bounds__(64) void splitk_finalize_tile_kernel(const ConvArgs a)
 {
     static_assert(EPI == EPI_PLAIN || EPI == EPI_POOL, "a fused head is never K-split");
     constexpr int WAVES_C = BN / 64;
     constexpr int NF = conv_wave_frags(BN, TH, TW);
-    int t = blockIdx.x;                       // = the conv's logical tile index (its slab record)
+    int t = blockIdx.x >> 2;                  // = the conv's logical tile index (its slab record)
     const int tile = t;
     const int ct = t % a.nct; t /= a.nct;
     const int tx = t % a.tilesX; t /= a.tilesX;
     const int ty = t % a.tilesY;
     const int b = t / a.tilesY;
-    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63, wave = blockIdx.x & 3;   // the conv wave whose fragments this workgroup reduces
     const int l15 = lane & 15, lc = lane >> 4;
     const int wc = wave % WAVES_C, wp = wave / WAVES_C;
     const int ntile = a.B * a.tilesY * a.tilesX * a.nct;

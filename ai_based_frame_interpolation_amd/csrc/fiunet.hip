@@ -10,6 +10,7 @@
 #include "../../include/fiunet.h"
 #include "pointwise.hip.h"
 #include "conv3x3_pair.hip.h"
+#include "conv3x3_kwave.hip.h"
 #include "metrics.hip.h"
 
 #include <algorithm>
@@ -155,12 +156,17 @@ struct PlanOpts {
 // (upsample_kernel) and gathered by plain LDS-DMA like the skip half.  bf16 only: on the fp32 matrix
 // cores the interpolation is small beside the 16x slower MFMAs, and the tensor twice as big.
 // Small problems (launch-bound, K-split) keep the fused gather: `pixels` = B x H x W at the stage's level.
-inline bool materialise_up(int stage, int precision, bool unfused, long long pixels, const int* cout = kCoutBil,
+// Small problems keep the fused gather - unless the conv then qualifies for the in-workgroup K cut (conv3x3_kwave.hip.h,
+// direct sources only): a quarter of the serial step chain is worth the extra upsample dispatch (ONE 256x256 pair: up1.0
+// 34 -> 23 us, up2.0 30 -> 18 us).  B, H, W: the stage's level.
+inline bool kwave_applies(int B, int H, int W, int Cin, int Cout);
+inline bool materialise_up(int stage, int precision, bool unfused, int B, int H, int W, const int* cout = kCoutBil,
                            bool convt = false)
 {
     if (convt || precision == FIUNET_BF16X2) return kMode[stage] == SRC_CONCAT_UP;   // (no in-gather form for these)
-    return precision == FIUNET_BF16 && !unfused && kMode[stage] == SRC_CONCAT_UP && cout[stage] >= 256 &&
-           pixels >= 65536;
+    if (precision != FIUNET_BF16 || unfused || kMode[stage] != SRC_CONCAT_UP) return false;
+    if (cout[stage] >= 256 && (long long)B * H * W >= 65536) return true;
+    return kwave_applies(B, H, W, cout[kSrc0[stage]] + cout[kSrc1[stage]], cout[stage]);
 }
 
 bool make_plan(int B, int H, int W, int precision, const PlanOpts& o, Plan& p)
@@ -191,8 +197,7 @@ bool make_plan(int B, int H, int W, int precision, const PlanOpts& o, Plan& p)
     }
     for (int i = 0; i < NCONV; ++i) {
         p.up_off[i] = 0;
-        if (materialise_up(i, precision, o.unfused || o.gather_up, (long long)B * p.hs[kLevel[i]] * p.ws[kLevel[i]], o.cout,
-                           o.convt))
+        if (materialise_up(i, precision, o.unfused || o.gather_up, B, p.hs[kLevel[i]], p.ws[kLevel[i]], o.cout, o.convt))
             bufs.push_back({align256((size_t)B * p.hs[kLevel[i]] * p.ws[kLevel[i]] *
                                      (o.convt ? o.cout[kSrc1[i]] / 2 : o.cout[kSrc1[i]]) * es), i,
                             o.keep_all ? END : i, &p.up_off[i]});
@@ -378,7 +383,7 @@ inline bool prefer_wide(int H, int W, int THw, int TWw, int THn, int TWn)
 // for B >= 2 (a SINGLE pair with 64..127 workgroups per image, e.g. the deepest level of a 720p frame, is); small frames,
 // where a single pair is cut anyway, below 256.  fiunet_min_unsplit_batch answers from the same function.
 struct TileShape { int BN, TH, TW; };
-struct ConvCfg { bool small; int ksplit; };
+struct ConvCfg { bool small; int ksplit; bool kwave = false; };   // kwave: the K loop cut over the four waves of a workgroup (conv3x3_kwave.hip.h)
 
 inline TileShape big_tile(int H, int W, int Cout)
 {
@@ -421,8 +426,22 @@ inline int small_ksplit(bool fp32, long long nblk, int nplanes, bool concat)
 
 // `splittable`: plain / pooled epilogue with a slab to write to (never the fused stem or the fused head).
 // force_small: -1 = choose, 0 / 1 = debug override; force_ksplit: 0 = choose, k >= 1 = debug override (powers of two).
+// Would a bf16 direct conv of this shape take conv3x3_kwave_kernel?  >= 4 planes of K (one per wave), at most one
+// workgroup per CU (136 KiB of LDS each), a problem the tuned tile cannot fill the chip with, and the batch-invariance gate
+// of every K cut (it IS one: the fp32 summation order changes).
+inline bool kwave_applies(int B, int H, int W, int Cin, int Cout)
+{
+    const TileShape big = big_tile(H, W, Cout);
+    const long long nblk_big = tile_blocks(big, B, H, W, Cout);
+    if (nblk_big >= 256 || !(nblk_big < (nblk_big / B < 64 ? 256 : 128))) return false;
+    const long long nwg = (long long)B * ((H + 1) / 2) * ((W + 31) / 32) * (Cout / 64);
+    return Cin / 32 >= 4 && Cout % 64 == 0 && nwg <= 256;
+}
+
+// kwave_ok: the launch has the form conv3x3_kwave_kernel covers (bf16, direct sources, plain / pooled epilogue).
+// force_small == 2: that kernel where it applies (diagnostic).
 inline ConvCfg choose_conv_cfg(bool fp32, bool x2, int B, int H, int W, int Cin, int Cout, bool splittable,
-                               int force_small = -1, int force_ksplit = 0, bool concat = false)
+                               int force_small = -1, int force_ksplit = 0, bool concat = false, bool kwave_ok = false)
 {
     const int PL = fp32 ? 16 : 32;
     const int nplanes = Cin / PL * (x2 ? 3 : 1);
@@ -431,6 +450,14 @@ inline ConvCfg choose_conv_cfg(bool fp32, bool x2, int B, int H, int W, int Cin,
     // the chip is full with the tuned tile: whole K loop, nothing to choose
     if (nblk_big >= 256 && force_small < 0 && force_ksplit <= 0) return ConvCfg{false, 1};
     const bool may_split = splittable && nblk_big < (nblk_big / B < 64 ? 256 : 128);
+    // bf16, direct sources, >= 4 planes of K, at most one workgroup per CU: the K loop cut over the WAVES of a workgroup
+    // (conv3x3_kwave.hip.h) - a quarter of the serial step chain with no slab and no reduction dispatch (kwave_applies).
+    // (bf16x2 runs nine steps per real plane: from 16 planes on its per-wave chain is longer than what a cross-workgroup cut
+    // of 8 leaves - ONE 256x256 pair, down4: 34 us against 26 - so there the slab form stays; profiles/r06_cfg_sweep_b1_256_bf16x2.txt)
+    if (kwave_ok && !fp32 && splittable && Cin / 32 >= 4 && (force_small == 2 || (force_small < 0 && force_ksplit <= 0))) {
+        if (force_small == 2 || (kwave_applies(B, H, W, Cin, Cout) && !(x2 && Cin / 32 > 8))) return ConvCfg{true, 1, true};
+    }
+    if (force_small == 2) force_small = 1;
     auto big_ksplit = [&]() {   // the rule of rounds 1-5 for the tuned tiles (powers of two)
         int k = (int)std::min<long long>(std::min(nplanes / 2, 16), (256 + nblk_big - 1) / nblk_big);
         k = k > 1 ? pow2_floor(k) : 1;
@@ -465,6 +492,33 @@ inline ConvCfg choose_conv_cfg(bool fp32, bool x2, int B, int H, int W, int Cin,
 template <typename T, int BN, int TH, int TW, int MODE, int EPI>
 constexpr bool pair_capable() { return MODE == SRC_DIRECT && (EPI == EPI_PLAIN || EPI == EPI_POOL) && BN == 128; }
 
+// The K loop cut over the four waves of a workgroup (small problems, bf16, direct sources): conv3x3_kwave.hip.h.
+template <int EPI, bool X2> int launch_kwave(ConvArgs a, hipStream_t s)
+{
+    using Tile = KWaveTile;
+    if (g_name_out) {
+        char buf[96];
+        std::snprintf(buf, sizeof buf, "conv3x3_kwave_kernel<bf16%s,64,2,32,%d>+kwave4", X2 ? "x2" : "", EPI);
+        *g_name_out = buf;
+    }
+    a.tilesX = (a.W + Tile::TW - 1) / Tile::TW;
+    a.tilesY = (a.H + Tile::TH - 1) / Tile::TH;
+    a.nct = a.Cout / Tile::BN;
+    const long long nblk = (long long)a.B * a.tilesX * a.tilesY * a.nct;
+    if (nblk <= 0 || nblk > 0x7fffffffLL) return fail(FIUNET_ERR_INVALID_ARG, "conv grid too large");
+    static std::atomic<bool> lds_attr_set[64];
+    int dev = 0;
+    HIP_TRY(hipGetDevice(&dev));
+    if (dev >= 0 && dev < 64 && !lds_attr_set[dev].load(std::memory_order_acquire)) {
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_kwave_kernel<EPI, X2>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, Tile::LDS_BYTES));
+        lds_attr_set[dev].store(true, std::memory_order_release);
+    }
+    hipLaunchKernelGGL((conv3x3_kwave_kernel<EPI, X2>), dim3((unsigned)nblk), dim3(256), Tile::LDS_BYTES, s, a);
+    HIP_TRY(hipGetLastError());
+    return FIUNET_OK;
+}
+
 // One conv launch in a given tile shape; ksplit > 1: the K loop (planes) cut over `ksplit` workgroups that store raw
 // fp32 partial sums, then splitk_finalize_tile_kernel adds them in slice order (deterministic) and runs the epilogue.
 template <typename T, int BN, int TH, int TW, int MODE, int EPI>
@@ -480,7 +534,7 @@ int launch_conv_maybe_split(ConvArgs a, hipStream_t s, int ksplit)
             k.tilesY = (a.H + TH - 1) / TH;
             k.nct = a.Cout / BN;
             const long long ntile = (long long)a.B * k.tilesX * k.tilesY * k.nct;
-            hipLaunchKernelGGL((splitk_finalize_tile_kernel<T, BN, TH, TW, EPI, src_is_x2(MODE)>), dim3((unsigned)ntile), dim3(256), 0, s, k);
+            hipLaunchKernelGGL((splitk_finalize_tile_kernel<T, BN, TH, TW, EPI, src_is_x2(MODE)>), dim3((unsigned)(4 * ntile)), dim3(64), 0, s, k);
             HIP_TRY(hipGetLastError());
             if (g_name_out) *g_name_out += "+splitk" + std::to_string(ksplit);
             return FIUNET_OK;
@@ -521,8 +575,13 @@ template <typename T, int MODE, int EPI> int launch_conv_shape(const ConvArgs& a
     constexpr bool splittable_kind = !src_is_stem(MODE) && (EPI == EPI_PLAIN || EPI == EPI_POOL);
     if (a.Cout != 64 && a.Cout % 128 != 0) return fail(FIUNET_ERR_INVALID_ARG, "Cout must be 64 or k*128");
     if ((EPI == EPI_HEAD || EPI == EPI_HEAD3) && a.Cout != 64) return fail(FIUNET_ERR_INVALID_ARG, "fused head needs Cout == 64");
+    constexpr bool kwave_kind = sizeof(T) == 2 && (MODE == SRC_DIRECT || MODE == SRC_DIRECT_X2) && (EPI == EPI_PLAIN || EPI == EPI_POOL);
     const ConvCfg cfg = choose_conv_cfg(sizeof(T) == 4, src_is_x2(MODE), a.B, a.H, a.W, a.C0 + a.C1, a.Cout,
-                                        splittable_kind && a.kslab && a.dst, a.force_tile - 1, a.force_ksplit);
+                                        splittable_kind && a.kslab && a.dst, a.force_tile - 1, a.force_ksplit,
+                                        MODE == SRC_CONCAT_UP, kwave_kind);
+    if constexpr (kwave_kind) {
+        if (cfg.kwave) return launch_kwave<EPI, MODE == SRC_DIRECT_X2>(a, s);
+    }
     if (cfg.small) return launch_conv_maybe_split<T, 64, 8, 32, MODE, EPI>(a, s, cfg.ksplit);
     if (a.Cout == 64) {
         const bool wide = prefer_wide(a.H, a.W, 16, 32, 32, 16);
@@ -727,7 +786,7 @@ int forward_impl(fiunet_ctx* ctx, const float* f1, const float* f2, float* out, 
             a.src0 = scratch; a.C0 = a.C0 + a.C1; a.C1 = 0; a.src1 = nullptr; mode = SRC_DIRECT;
         }
         if (mode == SRC_CONCAT_UP &&
-            materialise_up(i, bf16 ? FIUNET_BF16 : FIUNET_FP32, unfused || po.gather_up, (long long)B * a.H * a.W, ctx->cout)) {
+            materialise_up(i, bf16 ? FIUNET_BF16 : FIUNET_FP32, unfused || po.gather_up, B, a.H, a.W, ctx->cout)) {
             T* up = (T*)(ws + p.up_off[i]);
             const dim3 grid((unsigned)((a.W * 4 + 255) / 256), (unsigned)((a.H + UPS_ROWS - 1) / UPS_ROWS),
                             (unsigned)(B * (a.C1 / Elem<T>::PL)));
@@ -1175,8 +1234,13 @@ int fiunet_min_unsplit_batch(const fiunet_ctx* ctx, int H, int W, int precision)
         // the ablation / read-back paths either, so that both accumulate in the same order)
         for (int i = 1; i < NCONV - 1 && !split; ++i) {
             if (i == 1 && po.fused_stem) continue;            // SRC_STEM launches are never cut
-            split = choose_conv_cfg(precision == FIUNET_FP32, precision == FIUNET_BF16X2, B, hs[kLevel[i]], ws[kLevel[i]],
-                                    ctx->conv[i].cin, ctx->cout[i], true, ctx->force_tile[i] - 1, ctx->force_ksplit[i]).ksplit > 1;
+            const ConvCfg c = choose_conv_cfg(precision == FIUNET_FP32, precision == FIUNET_BF16X2, B, hs[kLevel[i]], ws[kLevel[i]],
+                                              ctx->conv[i].cin, ctx->cout[i], true, ctx->force_tile[i] - 1, ctx->force_ksplit[i],
+                                              kMode[i] == SRC_CONCAT_UP,
+                                              precision != FIUNET_FP32 &&
+                                                  (kMode[i] != SRC_CONCAT_UP || po.unfused ||
+                                                   materialise_up(i, precision, po.unfused || po.gather_up, B, hs[kLevel[i]], ws[kLevel[i]], ctx->cout, po.convt)));
+            split = c.ksplit > 1 || c.kwave;
         }
         if (!split) return B;
     }
@@ -1457,11 +1521,11 @@ int fiunet_postprocess_u8(const float* in, uint8_t* out, size_t n, void* stream)
 }
 
 // diagnostic (not part of the ABI, no declaration in include/fiunet.h): override choose_conv_cfg for one conv (1..17) of
-// this context - tile: 0 = choose, 1 = big, 2 = small; ksplit: 0 = choose, k >= 1 = cut the K loop k ways where the launch
+// this context - tile: 0 = choose, 1 = big, 2 = small, 3 = the in-workgroup K cut (conv3x3_kwave_kernel) where it applies; ksplit: 0 = choose, k >= 1 = cut the K loop k ways where the launch
 // can be cut.  tools/cfg_sweep.py times every candidate of every layer with it; layer < 0 clears all overrides.
 int fiunet_debug_force_cfg(fiunet_ctx* ctx, int layer, int tile, int ksplit)
 {
-    if (!ctx || layer >= NCONV || tile < 0 || tile > 2 || ksplit < 0 || ksplit > 32)
+    if (!ctx || layer >= NCONV || tile < 0 || tile > 3 || ksplit < 0 || ksplit > 32)
         return fail(FIUNET_ERR_INVALID_ARG, "fiunet_debug_force_cfg: bad arguments");
     if (layer < 0) {
         for (int i = 0; i < NCONV; ++i) ctx->force_tile[i] = ctx->force_ksplit[i] = 0;
@@ -1559,7 +1623,7 @@ int fiunet_debug_read_activation(fiunet_ctx* ctx, const void* workspace, int B, 
         const int i = 10 + 2 * (tap - NCONV);
         lv = kLevel[i];
         const PlanOpts po = plan_opts(ctx, H, W, precision);
-        if (!materialise_up(i, precision, po.unfused || po.gather_up, (long long)B * p.hs[lv] * p.ws[lv], ctx->cout, po.convt))
+        if (!materialise_up(i, precision, po.unfused || po.gather_up, B, p.hs[lv], p.ws[lv], ctx->cout, po.convt))
             return fail(FIUNET_ERR_UNSUPPORTED, "read-back: the upsampled half of this stage is interpolated inside the "
                                                 "conv's gather in this configuration, never stored");
         C = po.convt ? ctx->cout[kSrc1[i]] / 2 : ctx->cout[kSrc1[i]];

@@ -930,6 +930,15 @@ def fp32_legs(dev):
     return out
 
 
+def _concat_stage_launches_upsample(name: str) -> bool:
+    """conv3x3_mfma_kernel<T,BN,TH,TW,MODE,EPI>: MODE 2 interpolates the upsampled half inside its gather; every other form
+    of a concat stage (direct two-source conv, conv3x3_kwave_kernel) reads it from a tensor an upsample launch wrote."""
+    if "conv3x3_mfma_kernel<" not in name:
+        return "_kernel<" in name
+    args = name.split("<", 1)[1].split(">", 1)[0].split(",")
+    return len(args) >= 5 and args[4].strip() != "2"
+
+
 def small_frames_leg(dev):
     """north_star: "throughput on synthetic 256x256 and 1080p pairs ... as fraction of the roofline".  (a) `latency_256`:
     ONE 256x256 pair - the only size the reference itself ever runs (model/inference.py:29,101-122 resize every input to
@@ -968,11 +977,13 @@ def small_frames_leg(dev):
                      "roofline": {"bound": "mfma", "achieved": round(tf * mult, 1), "peak": peak, "unit": "TFLOP/s",
                                   "frac": round(tf * mult / peak, 4),
                                   "note": "executed MFMA rate of the whole forward (bf16x2: 3 MFMAs per product)"},
-                     # 17 conv launches + one reduce pass per K-cut stage (it also pools), the stem where it is not fused,
-                     # bf16x2's four upsample launches
+                     # 17 conv launches + one reduce pass per cross-workgroup K cut (it also pools), the stem where it is not
+                     # fused, one upsample launch per concat conv (stages 10, 12, 14, 16) that does not interpolate inside its
+                     # own gather (gather mode 2 in the kernel's name)
                      "dispatches_per_forward": 17 + sum("+splitk" in r[0] for r in rows) + (0 if "fused" in rows[0][0] else 1)
-                                               + (4 if prec == "bf16x2" else 0),
-                     "k_split_stages": sum("+splitk" in r[0] for r in rows),
+                                               + sum(_concat_stage_launches_upsample(rows[i][0]) for i in (10, 12, 14, 16)),
+                     "cross_workgroup_k_cut_stages": sum("+splitk" in r[0] for r in rows),
+                     "in_workgroup_k_cut_stages": sum("+kwave" in r[0] for r in rows),
                      "small_tile_stages": sum(",64,8,32," in r[0] for r in rows)}
         del m
     del f1, f2

@@ -551,3 +551,88 @@ def test_convtranspose_variant_per_layer_golden_fixture(convt_model, dev, golden
     want = g["unet.outc|val"]
     tol = FP32_TOL if prec != "bf16" else 0.04 * (want.max() - want.min())
     assert np.abs(got - want).max() <= tol
+
+
+# ---- round 6: the small-problem configuration (tile family, K cut) -----------------------------------------------------
+@pytest.mark.parametrize("prec", ["fp32", "bf16", "bf16x2"])
+def test_tile_family_never_changes_a_bit(model, dev, prec):
+    """The small tile (64 couts x 8x32 pixels, 64 x 64 wave tiles, 4-deep weight ring, its own fused-stem and fused-head
+    forms) against the tuned tiles on the same K cut: bit-identical on every stage - the summation order of an output
+    element is (plane, kx, ky) in every tile shape and the fused head reduces in the same association.  Sizes: one that
+    the default configuration runs on small tiles (64x96) and one it runs on tuned tiles (2 x 270x480), each forced
+    both ways with the K loop whole."""
+    model.precision = prec
+    model.set_options()
+    for b, h, w in ((1, 64, 96), (2, 270, 480)):
+        f1, f2 = O.make_frames(41, b, h, w)
+        f1, f2 = f1.to(dev), f2.to(dev)
+        model(f1, f2)   # (creates the context)
+        outs = []
+        for tile in (1, 2):
+            for layer in range(1, 18):
+                model._ctx.force_cfg(layer, tile, 1)
+            outs.append(model(f1, f2).clone())
+        model._ctx.force_cfg(-1)
+        assert torch.equal(outs[0], outs[1]), (prec, b, h, w, (outs[0] - outs[1]).abs().max().item())
+    model.precision = "fp32"
+
+
+@pytest.mark.parametrize("prec", ["fp32", "bf16", "bf16x2"])
+def test_k_cut_is_deterministic_and_within_contract(model, dev, seeded_sd, prec):
+    """Every K cut (2 .. 16 slices, both tile families, the tile finalize with its fused pool) against the oracle: the
+    cut changes only where the fp32 partial sums meet, so fp32 / bf16x2 stay inside the 1e-3 contract and bf16 inside
+    its own; and a cut forward is deterministic."""
+    f1, f2 = O.make_frames(43, 2, 48, 80)
+    ref = O.unet_forward(seeded_sd, f1, f2)
+    d1, d2 = f1.to(dev), f2.to(dev)
+    model.precision = prec
+    model.set_options()
+    model(d1, d2)
+    for tile in (1, 2):
+        for k in (2, 4, 16):
+            for layer in range(1, 18):
+                model._ctx.force_cfg(layer, tile, k)
+            a = model(d1, d2)
+            assert torch.equal(a, model(d1, d2))
+            err = (a.cpu() - ref).abs().max().item()
+            if prec == "bf16":
+                assert ((a.cpu() - ref).norm() / ref.norm()).item() <= 2e-2
+            else:
+                assert err <= 1e-3, (prec, tile, k, err)
+    model._ctx.force_cfg(-1)
+    model.precision = "fp32"
+
+
+@pytest.mark.parametrize("prec", ["bf16", "bf16x2"])
+def test_in_workgroup_k_cut_kernel(model, dev, seeded_sd, prec):
+    """conv3x3_kwave_kernel (bf16 operands, direct sources, the K loop cut over the four waves of a workgroup, reduced
+    through LDS; in bf16x2 three virtual planes per real plane and a two-piece epilogue): forced onto every conv it
+    covers - plain and pooled epilogues, two-source direct convs (the materialised upsampled half), odd sizes with
+    partial tiles - it must be deterministic, position-invariant, and within the precision's contract of the oracle,
+    close to the default configuration's result (same products, another fp32 association)."""
+    model.precision = prec
+    model.set_options()
+    for b, h, w in ((1, 64, 96), (3, 33, 47), (2, 135, 240)):
+        f1, f2 = O.make_frames(47, b, h, w)
+        ref = O.unet_forward(seeded_sd, f1, f2)
+        d1, d2 = f1.to(dev), f2.to(dev)
+        base = model(d1, d2).clone()
+        for layer in range(1, 18):
+            model._ctx.force_cfg(layer, 3, 0)
+        model._ctx.profile_enable(True)
+        out = model(d1, d2).clone()
+        _, rows = model._ctx.profile_read()
+        model._ctx.profile_enable(False)
+        assert sum("kwave" in r[0] for r in rows) >= 8, [r[0] for r in rows]       # the direct convs with >= 4 planes
+        assert torch.equal(out, model(d1, d2))                                       # deterministic
+        perm = torch.roll(torch.arange(b), 1).to(dev)
+        rolled = model(d1[perm].contiguous(), d2[perm].contiguous())                # same batch size: the other layers' K cuts stay put
+        model._ctx.force_cfg(-1)
+        assert torch.equal(rolled, out[perm])                                        # position invariant
+        if prec == "bf16":
+            rel = ((out.cpu() - ref).norm() / ref.norm()).item()
+            assert rel <= 2e-2, (b, h, w, rel)
+            assert ((out - base).norm() / base.norm()).item() <= 1e-2
+        else:
+            assert (out.cpu() - ref).abs().max().item() <= 1e-3, (b, h, w, (out.cpu() - ref).abs().max().item())
+    model.precision = "fp32"

@@ -37,8 +37,8 @@ tot = 0.0
 for i in range(1, 18):
     chosen = base[i][0]
     seen = {}
-    for tile in (1, 2):
-        for k in (1, 2, 4, 8, 16, 32):
+    for tile, ks in ((1, (1, 2, 4, 8, 16, 32)), (2, (1, 2, 4, 8, 16, 32)), (3, (1,))):   # 3: the in-workgroup K cut where it applies
+        for k in ks:
             L.fiunet_debug_force_cfg(H, -1, 0, 0)
             L.fiunet_debug_force_cfg(H, i, tile, k)
             try:

@@ -16,6 +16,6 @@ for p in bf16 fp32; do
   timeout -k 10 200 rocprofv3 --kernel-trace --output-format csv -d $O/tr_$p -- python3 $R/tools/latency_trace.py $p > $O/lat_$p.log 2>&1 || { tail $O/lat_$p.log; exit 1; }
 done
 cd $R
-python tools/trace_forward.py $O/tr_bf16 ${DISPATCHES_BF16:-27} > $O/trace_bf16.txt; python tools/trace_forward.py $O/tr_fp32 ${DISPATCHES_FP32:-32} > $O/trace_fp32.txt
+python tools/trace_forward.py $O/tr_bf16 ${DISPATCHES_BF16:-40} > $O/trace_bf16.txt; python tools/trace_forward.py $O/tr_fp32 ${DISPATCHES_FP32:-40} > $O/trace_fp32.txt
 find $O -name "*.csv" -delete; find $O -name "*.db" -delete
 cat $O/trace_bf16.txt
