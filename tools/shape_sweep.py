@@ -1,6 +1,8 @@
-"""One-off wider sweep (GPU box): random batch / frame shapes, both precisions, HIP path vs the CPU oracle,
-plus default vs gather-upsample bit-equality (the unfused path's head reads the bf16-rounded last
-activation and its stem is the standalone fp32 kernel, so its OUTPUT is only close: <= 3e-2 relative).
+"""One-off wider sweep (GPU box): random batch / frame shapes, the three precisions, HIP path vs the CPU oracle,
+plus default vs gather-upsample and vs the unfused path (close, <= 1e-2 / 3e-2 relative: since round 6 the gather-upsample
+option changes the K cut of a small problem's concat convs - in-workgroup cut on the materialised half against a slab cut
+on the fused gather - so bit-equality of the two holds only where no layer is cut: tests/test_gpu_configs.py pins it there;
+the unfused path's head reads the bf16-rounded last activation and its stem is the standalone fp32 kernel).
 usage: python tools/shape_sweep.py [n_random=40]"""
 import os, sys, time
 import numpy as np, torch
@@ -33,10 +35,10 @@ for i, (b, h, w) in enumerate(shapes):
     m.set_options(gather_upsample=True); og = m(g1, g2)
     m.set_options(unfused=True); ou = m(g1, g2)
     m.set_options()
-    eq = bool(torch.equal(o16, og)) and ((ou - o16).norm() / o16.norm()).item() <= 3e-2
+    eq = ((og - o16).norm() / o16.norm()).item() <= 1e-2 and ((ou - o16).norm() / o16.norm()).item() <= 3e-2
     worst32, worst16 = max(worst32, d), max(worst16, rel)
     okx2 = dx2 <= 1e-3 and dx2 <= 2e-4 * max(1.0, ref.abs().max().item())   # the fp32 contract, and relative
     flag = "" if (d <= 1e-4 and rel <= 2.5e-2 and eq and okx2 and torch.isfinite(o16).all()) else "  <-- FAIL"
-    print(f"{b}x{h}x{w}: fp32 rel-max {d:.2e}  bf16x2 max-abs {dx2:.2e}  bf16 rel-L2 {rel:.3e}  default==gather-upsample, unfused close: {eq}{flag}", flush=True)
+    print(f"{b}x{h}x{w}: fp32 rel-max {d:.2e}  bf16x2 max-abs {dx2:.2e}  bf16 rel-L2 {rel:.3e}  gather-upsample and unfused close to default: {eq}{flag}", flush=True)
     if flag: sys.exit(1)
 print(f"SWEEP OK: {len(shapes)} shapes, worst fp32 {worst32:.2e}, worst bf16x2 (relative to max(1, |ref|)) {worstx2:.2e}, worst bf16 {worst16:.3e}, {time.time() - t0:.0f} s")
