@@ -1536,6 +1536,24 @@ int fiunet_debug_force_cfg(fiunet_ctx* ctx, int layer, int tile, int ksplit)
     return FIUNET_OK;
 }
 
+// diagnostic (not part of the ABI): what choose_conv_cfg answers for one conv launch - pure host arithmetic, no device
+// call, so the rule (tile family, K cut, the batch-invariance gates) is testable without a GPU (tests/test_cfg_rule.py).
+// out[0] = 1 small tile, out[1] = K slices over workgroups, out[2] = 1 in-workgroup K cut (conv3x3_kwave_kernel),
+// out[3] = would a concat conv of this shape have its upsampled half materialised (stage index in `concat_stage`, 0 = n/a)
+int fiunet_debug_choose_cfg(int precision, int B, int H, int W, int Cin, int Cout, int splittable, int concat_stage,
+                            int kwave_ok, int* out /* [4] */)
+{
+    if (!out || B < 1 || H < 1 || W < 1 || Cin < 32 || (Cout != 64 && Cout % 128 != 0) ||
+        (precision != FIUNET_FP32 && precision != FIUNET_BF16 && precision != FIUNET_BF16X2))
+        return fail(FIUNET_ERR_INVALID_ARG, "fiunet_debug_choose_cfg: bad arguments");
+    const ConvCfg c = choose_conv_cfg(precision == FIUNET_FP32, precision == FIUNET_BF16X2, B, H, W, Cin, Cout, splittable != 0,
+                                      -1, 0, concat_stage != 0, kwave_ok != 0);
+    out[0] = c.small; out[1] = c.ksplit; out[2] = c.kwave;
+    out[3] = concat_stage >= 10 && concat_stage < NCONV && kMode[concat_stage] == SRC_CONCAT_UP
+                 ? materialise_up(concat_stage, precision, false, B, H, W) : 0;
+    return FIUNET_OK;
+}
+
 #if defined(FIUNET_STAMP) || defined(FIUNET_CLOCK)
 // diagnostic builds only (not part of the ABI): stamp ONE stage per forward; read = sums over waves
 int fiunet_debug_stamp_layer(fiunet_ctx* ctx, int layer)
