@@ -832,8 +832,8 @@ int forward_impl(fiunet_ctx* ctx, const float* f1, const float* f2, float* out, 
 // SRC_DIRECT_X2 (three virtual planes per real plane: (xh, wh), (xh, wl) on the same in-tile, (xl, wh)), the stem is the
 // exact-fp32 kernel with a splitting epilogue, the upsampled halves are always materialised (x2_upsample_kernel: fp32
 // interpolation of hi + lo; bilinear=False: convt2x2_kernel<bf16, X2>), the head is the usual fused fp32 reduction.
-// Small problems K-split like the other precisions (splitk_finalize_kernel writes the two pieces, x2_maxpool2_kernel
-// the pooled copy).  FIUNET_OPT_KEEP_ALL keeps every activation for the read-back; no ablation path.
+// Small problems cut K like the other precisions (choose_conv_cfg: over workgroups with the tile reduce pass, or over the waves of
+// a workgroup).  FIUNET_OPT_KEEP_ALL keeps every activation for the read-back; no ablation path.
 int forward_x2(fiunet_ctx* ctx, const float* f1, const float* f2, float* out, int B, int H, int W, char* ws,
                const Plan& p, hipStream_t s, int y_origin, int Hg, uint8_t* out_u8, const uint8_t* u1 = nullptr,
                const uint8_t* u2 = nullptr, size_t out_img_stride = 0)

@@ -559,32 +559,6 @@ __global__ __launch_bounds__(256) void upsample_kernel(const ConvArgs a, T* __re
     }
 }
 
-// MaxPool2d(2) of a two-piece tensor (the K-split path of small problems; the un-split convs pool in their epilogue):
-// max of the four fp32 values hi + lo, split again.  src [B][2 * C/32][H][W][32] -> dst [B][2 * C/32][H/2][W/2][32].
-__global__ __launch_bounds__(256) void x2_maxpool2_kernel(const char* __restrict__ src, char* __restrict__ dst, int B, int H, int W, int C)
-{
-    const int np = C / 32, Ho = H / 2, Wo = W / 2;
-    const size_t HW = (size_t)H * W, HWo = (size_t)Ho * Wo;
-    const size_t blk = (size_t)np * HW * 64, oblk = (size_t)np * HWo * 64;
-    const size_t total = (size_t)B * np * HWo * 4;
-    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
-        const int ch = (int)(i & 3);
-        size_t r = i >> 2;
-        const int x = (int)(r % Wo); r /= Wo;
-        const int y = (int)(r % Ho); r /= Ho;
-        const int p = (int)(r % np), b = (int)(r / np);
-        const char* base = src + (size_t)b * 2 * blk + ((size_t)p * HW + (size_t)(2 * y) * W + 2 * x) * 64 + ch * 16;
-        float a0[8], a1[8], a2[8], a3[8], o[8];
-        x2_load(base, blk, a0);
-        x2_load(base + 64, blk, a1);
-        x2_load(base + (size_t)W * 64, blk, a2);
-        x2_load(base + (size_t)W * 64 + 64, blk, a3);
-#pragma unroll
-        for (int k = 0; k < 8; ++k) o[k] = fmaxf(fmaxf(a0[k], a1[k]), fmaxf(a2[k], a3[k]));
-        x2_split_store(dst + (size_t)b * 2 * oblk + ((size_t)p * HWo + (size_t)y * Wo + x) * 64 + ch * 16, oblk, o);
-    }
-}
-
 // Upsample(x2, bilinear, align_corners=True) + F.pad of a two-piece tensor: the fp32 value hi + lo of the four
 // neighbours, aten's association in fp32 (chunk_bilerp's), split again.  a.src1 = low-res [B][2 * C1/32][lowH][lowW][32],
 // dst = [B][2 * C1/32][H][W][32]; a.C1 = the REAL channel count.  Same work split as upsample_kernel: grid =
@@ -678,57 +652,6 @@ __global__ __launch_bounds__(256) void head1x1_kernel(const T* __restrict__ src,
     }
     const size_t b = i / HW, p = i - b * HW;
     for (int k = 0; k < nc; ++k) out[(b * nc + k) * HW + p] = acc[k] + bias[k];
-}
-
-// Split-K finalize (small problems): out = relu(scale * sum_s slab[s] + shift), slices added in
-// index order (deterministic); slab is [ksplit][B*H*W][C] fp32, out is the blocked layout.
-// thread = (pixel, 16-byte output chunk)
-template <typename T>
-__global__ __launch_bounds__(256) void splitk_finalize_kernel(const float* __restrict__ slab, int ksplit,
-                                                              const float* __restrict__ scale,
-                                                              const float* __restrict__ shift,
-                                                              T* __restrict__ dst, int B, int H, int W,
-                                                              int C, int relu, int x2 = 0)
-{
-    // x2 != 0 (precision bf16x2, T = bf16): dst is the two-piece tensor of 2 * C channels [hi | lo]
-    constexpr int NE = Elem<T>::NE, PL = Elem<T>::PL;
-    const int cpp = C / NE;  // chunks per pixel
-    const size_t npix = (size_t)B * H * W, total = npix * cpp;
-    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
-        const int cc = (int)(i % cpp);
-        const size_t pix = i / cpp;
-        const int c0 = cc * NE;
-        float v[NE];
-#pragma unroll
-        for (int e = 0; e < NE; ++e) v[e] = 0.f;
-        for (int s = 0; s < ksplit; ++s) {
-            const float* p = slab + ((size_t)s * npix + pix) * C + c0;
-#pragma unroll
-            for (int e = 0; e < NE; e += 4) {
-                const float4 q = *reinterpret_cast<const float4*>(p + e);
-                v[e] += q.x; v[e + 1] += q.y; v[e + 2] += q.z; v[e + 3] += q.w;
-            }
-        }
-#pragma unroll
-        for (int e = 0; e < NE; ++e) {
-            v[e] = scale ? fmaf(v[e], scale[c0 + e], shift[c0 + e]) : v[e] + shift[c0 + e];  // scale == nullptr: folded into the weights
-            if (relu) v[e] = fmaxf(v[e], 0.f);
-        }
-        const size_t b = pix / ((size_t)H * W), r = pix - b * (size_t)H * W;
-        if constexpr (sizeof(T) == 2) {
-            if (x2) {
-                const size_t blk = (size_t)(C / 32) * H * W * 64;
-                float w8[8];
-#pragma unroll
-                for (int e = 0; e < 8; ++e) w8[e] = v[e];
-                x2_split_store((char*)dst + b * 2 * blk + ((size_t)(c0 / 32) * H * W + r) * 64 + (size_t)(c0 % 32) * 2, blk, w8);
-                continue;
-            }
-        }
-        char* o = (char*)dst + b * (size_t)H * W * C * sizeof(T) + ((size_t)(c0 / PL) * H * W + r) * 64 +
-                  (size_t)(c0 % PL) * sizeof(T);
-        *reinterpret_cast<uint4*>(o) = chunk_pack<T>(v);
-    }
 }
 
 template <typename T>
