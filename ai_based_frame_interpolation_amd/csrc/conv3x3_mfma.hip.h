@@ -490,14 +490,10 @@ template <int BN, int TH, int TW, int MODE> struct ConvTile {
     static constexpr int SPARE_BYTES =
         (MODE == SRC_CONCAT_UP && LR_PIECES * 1024 > W_BYTES) ? LR_PIECES * 1024 - W_BYTES : 0;
     static constexpr int W_STRIDE = W_BYTES + SPARE_BYTES;  // slot 1 = slot 0 + W_STRIDE
-    // Depth of the weight ring.  Two slots (W(step+1) lands under the MFMAs of `step`) are what the 64 x 128 wave tiles
-    // have LDS for at two workgroups per CU - and all they need: a step is 96 MFMAs per wave and the weights of a layer
-    // that fills the chip are L2 hits.  The 64 x 64 wave tiles are the small-problem configuration (fiunet.hip,
-    // choose_conv_cfg): one or two workgroups per CU, every (cout tile, K slice) streams weights nobody else has touched
-    // (Infinity Cache / HBM latency) and a step is 48 MFMAs - there the ring is FOUR deep (W(step+3) requested at the top of
-    // `step`: a whole plane ahead), which costs 24 KiB of LDS nobody is using.
-    // (three with the fused stem, whose patch and parked weights take 7.5 KiB of the 80)
-    static constexpr int W_SLOTS = (TH * TW / 16 / (4 / (BN / 64)) == 4 && SPARE_BYTES == 0) ? (src_is_stem(MODE) ? 3 : 4) : 2;
+    // (Two ring slots.  A 4-deep ring for the small tiles - W(step+3) requested at the top of `step`, counted waits - was built in
+    // round 6 and measured NULL on the small problems it was meant for (a lone workgroup's step is issue / LDS latency, not L2
+    // latency: profiles/r06_cfg_sweep_b1_256_bf16_first_version.txt against r06_cfg_sweep_b1_256_bf16.txt), and its 24 KiB cost the
+    // small tile its third workgroup per CU, which IS worth 5-17 % on the deep levels of one to four 1080p pairs.)
     // SRC_STEM: raw patch of both frames, (TH+4) x (TW+4) pixels, after the ring: bf16 dwords {frame1,
     // frame2}, the hi and the lo part of a patch row side by side, [row][hi | lo][PATCH_W].  The row pitch
     // of 2 * PATCH_W = 72 dwords makes rows py and py+2 - read together by lane groups 0 and 1 of a
@@ -505,7 +501,7 @@ template <int BN, int TH, int TW, int MODE> struct ConvTile {
     // and lo images of pitch 36 put rows py, py+1 only 4 banks apart: 2-way conflicts on 12 of 16 lanes).
     static constexpr int PATCH_W = TW + 4, PATCH_H = TH + 4, PATCH_PITCH = 2 * PATCH_W;
     static_assert(!src_is_stem(MODE) || (2 * PATCH_PITCH) % 32 == 16, "patch pitch: lane groups 0/1 must not share banks");
-    static constexpr int PATCH_OFF = IN_BYTES + W_SLOTS * W_BYTES + SPARE_BYTES;
+    static constexpr int PATCH_OFF = IN_BYTES + 2 * W_BYTES + SPARE_BYTES;
     // The operand of the bias k-slot - PATCH_W dwords {1.0, 0} followed by PATCH_W zero dwords (its lo
     // part), which all lanes of lane group 3 read at the same address (a broadcast) - lives in the
     // row-pitch filler of in-tile row 0 (pixels TW+2 .. TWP-1: never written or read in this mode), so
@@ -998,7 +994,6 @@ __global__ __launch_bounds__(256, conv_occupancy(BN, TH, TW, ConvTile<BN, TH, TW
     // ---- weight stream: each wave moves NW 1-KiB pieces (16 LDS rows) per step by LDS-DMA.  The
     //      LDS image is lane-linear, so the XOR swizzle goes on the per-lane SOURCE chunk. --------
     constexpr int NW = Tile::W_BYTES / 1024 / 4;
-    constexpr int NSLOT = Tile::W_SLOTS;   // ring depth: W(step + NSLOT - 1) is requested at the top of `step`
     // Piece j of this wave = packed rows r0 .. r0+15 with r0 = (wave * NW + j) * 16; 16 divides BN, so a
     // piece lies inside one tap: its source offset is a wave-uniform part (added to the SGPR base) plus
     // ONE per-lane register shared by all pieces (row within the piece, swizzled 16-B chunk).
@@ -1013,7 +1008,7 @@ __global__ __launch_bounds__(256, conv_occupancy(BN, TH, TW, ConvTile<BN, TH, TW
         }
         const char* wsrc = wbase + ((size_t)(pl * 9 + kx * 3) * a.Cout) * 64;  // packed [plane][kx][ky][cout]
         const unsigned dst = __builtin_amdgcn_readfirstlane(
-            lds_w_addr + (unsigned)((step % NSLOT) * Tile::W_STRIDE + wave * NW * 1024));
+            lds_w_addr + (unsigned)((step & 1) * Tile::W_STRIDE + wave * NW * 1024));
 #pragma unroll
         for (int j = 0; j < NW; ++j) {
             const int r0 = (wave * NW + j) * 16, tap = r0 / BN;  // tap = ky within the step
@@ -1027,12 +1022,6 @@ __global__ __launch_bounds__(256, conv_occupancy(BN, TH, TW, ConvTile<BN, TH, TW
 #endif
 #ifdef FIUNET_DIAG_NO_WSTREAM
     if (nsteps > 1) issue_w(1);   // both ring slots hold real weights (realistic operand data, hence realistic power); nothing streams afterwards
-#else
-    if constexpr (NSLOT > 2) {    // deeper ring: the weights of steps 1 .. NSLOT-2 go out with W(0)
-#pragma unroll
-        for (int k = 1; k < NSLOT - 1; ++k)
-            if (k < nsteps) issue_w(k);
-    }
 #endif
     PSTAMP(10);
 
@@ -1188,8 +1177,7 @@ __global__ __launch_bounds__(256, conv_occupancy(BN, TH, TW, ConvTile<BN, TH, TW
     auto gather_plane_up = [&](int plane, int idle_slot) __attribute__((always_inline)) {
         constexpr int LRP = Tile::LRP, LRH = Tile::LRH;
         // idle slot 0: [slot0 | spare]; idle slot 1: [spare | slot1]
-        // (deeper rings exist only where the staging tile fits one slot: no spare region, any idle slot will do)
-        const int stg_off = NSLOT > 2 ? idle_slot * Tile::W_STRIDE : (idle_slot == 0 ? 0 : Tile::W_BYTES);
+        const int stg_off = idle_slot == 0 ? 0 : Tile::W_BYTES;
         const char* const lsrc = (const char*)a.src1 + (size_t)b * a.lowH * a.lowW * a.C1 * sizeof(T) +
                                  (size_t)(plane - p0) * a.lowH * a.lowW * 64;
         int opq = 0;
@@ -1531,12 +1519,11 @@ __global__ __launch_bounds__(256, conv_occupancy(BN, TH, TW, ConvTile<BN, TH, TW
     // the first in-tile gather of every kernel that fetches it by DMA - the kernel as it would run if a cross-tile prefetch
     // had delivered both for free (the upper bound of lever (a)); -DFIUNET_DIAG_NO_WSTREAM drops the whole weight stream - the
     // upper bound of weights held in LDS for the kernel's lifetime (lever (b))
-    // (staging area of an upsampled first plane - a K slice may start in the upsampled half: the slot no prologue request
-    // went to, i.e. the last one)
+    // (staging area of an upsampled first plane - a K slice may start in the upsampled half: slot 1, W(0) being in slot 0)
 #ifdef FIUNET_DIAG_FREE_PROLOGUE
-    if constexpr (STEM || MODE == SRC_CONCAT_UP) gather_plane(pbeg, NSLOT - 1, true);
+    if constexpr (STEM || MODE == SRC_CONCAT_UP) gather_plane(pbeg, 1, true);
 #else
-    gather_plane(pbeg, NSLOT - 1, true);
+    gather_plane(pbeg, 1, true);
 #endif
     PSTAMP(13);
     lds_dma_wait_all();
@@ -1560,14 +1547,10 @@ __global__ __launch_bounds__(256, conv_occupancy(BN, TH, TW, ConvTile<BN, TH, TW
         for (int kx = 0; kx < 3; ++kx, ++step) {
             // W(step) and the in-tile of `plane` are resident.  Stream W(step+1) into the other
             // ring slot (its last readers passed the barrier that ended step-1).
-            // (deeper ring: W(step + NSLOT - 1) into the slot step - 1 was read from; its readers passed that step's barrier)
 #ifndef FIUNET_DIAG_NO_WSTREAM
-            const bool w_issued = step + NSLOT - 1 < nsteps;
-            if (w_issued) issue_w(step + NSLOT - 1);
-#else
-            const bool w_issued = false;
+            if (step + 1 < nsteps) issue_w(step + 1);
 #endif
-            const char* wcur = lds_w + (step % NSLOT) * Tile::W_STRIDE + a_off;
+            const char* wcur = lds_w + (step & 1) * Tile::W_STRIDE + a_off;
             // this wave's in-tile rows 0 .. ROWS_W+1 at column offset kx: row i serves tap ky for the
             // output row i - ky, so every fragment is read once and used by up to three taps
             // Last step of a plane whose successor arrives by plain LDS-DMA: after the load of the last
@@ -1603,7 +1586,7 @@ __global__ __launch_bounds__(256, conv_occupancy(BN, TH, TW, ConvTile<BN, TH, TW
                         // in registers): once every wave is here the in-tile is dead and the next
                         // plane's DMA goes out, 64 MFMAs ahead of the boundary
                         __syncthreads();
-                        gather_plane(plane + 1, step % NSLOT, false);
+                        gather_plane(plane + 1, step & 1, false);
                     }
 #pragma unroll
                     for (int m = 0; m < 4; ++m)
@@ -1646,7 +1629,7 @@ __global__ __launch_bounds__(256, conv_occupancy(BN, TH, TW, ConvTile<BN, TH, TW
             STAMP(2);
             if (kx == 2 && gather_next && !early) {
                 __syncthreads();  // every wave is done with this plane's in-tile and with W(step)
-                gather_plane(plane + 1, step % NSLOT, false);
+                gather_plane(plane + 1, step & 1, false);
                 lds_dma_wait_all();
                 __syncthreads();
                 // fused x2 stem: every wave has read plane 0's parked weights for the last time (lo piece): plane 1's
@@ -1654,16 +1637,7 @@ __global__ __launch_bounds__(256, conv_occupancy(BN, TH, TW, ConvTile<BN, TH, TW
                 if constexpr (STEM && X2) { if (plane + 1 == 2) stem_park(1); }
                 STAMP(4);
             } else {
-                // this wave's pieces of W(step+1) landed.  Deeper ring: the (NSLOT - 2) * NW requests issued after them (the
-                // weights of the steps beyond) may stay in flight - loads return in order, so a counted wait is exact -
-                // unless this step issued the next plane's in-tile (early gather), which the next step reads: then everything
-                if (NSLOT > 2 && !early && w_issued) {
-                    if constexpr (NSLOT == 4 && NW == 3) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-                    else if constexpr (NSLOT == 3 && NW == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
-                    else lds_dma_wait_all();
-                } else {
-                    lds_dma_wait_all();
-                }
+                lds_dma_wait_all();   // this wave's pieces of W(step+1) landed
                 __syncthreads();      // ... and so have everyone else's
                 STAMP(3);
             }

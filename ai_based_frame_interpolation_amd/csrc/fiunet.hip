@@ -401,7 +401,7 @@ inline long long tile_blocks(const TileShape& t, int B, int H, int W, int Cout)
 // profiles/r06_cfg_sweep_*.txt).  What the sweep shows:
 //  * the small tile beats the big one on every layer of a problem the big tile cannot fill the chip with (12-35 %);
 //  * bf16: a lone workgroup's step (48 MFMAs, a barrier, the waits) takes ~0.6 us whatever is done about the weight
-//    stream (a 4-deep ring changed nothing), a dependent dispatch ~4.5 us, and the slab of a cut costs its bytes twice
+//    stream (a 4-deep ring changed nothing and was taken out), a dependent dispatch ~4.5 us, and the slab of a cut costs its bytes twice
 //    (k slices of the padded fp32 output written, then read back through the Infinity Cache at ~2.5-4.5 TB/s): cutting
 //    pays from 8 planes (24 serial steps) on, best at 2-4 planes per slice - k = 4 for 8 planes, 8 beyond;
 //  * fp32: a step is MFMA time (~3 us per 64 x 64 wave tile), so what counts is one workgroup on every CU: k = 256 /
@@ -440,15 +440,40 @@ inline bool kwave_applies(int B, int H, int W, int Cin, int Cout)
 
 // kwave_ok: the launch has the form conv3x3_kwave_kernel covers (bf16, direct sources, plain / pooled epilogue).
 // force_small == 2: that kernel where it applies (diagnostic).
+// Between one and a few ROUNDS of tuned-tile workgroups (512 resident slots) the last, partial round decides: 544
+// workgroups take 1.6 rounds' time (the 32 left over run alone), 480 take one.  The small tile - three workgroups per CU, 768
+// slots, twice the workgroups of half the size - quantises finer and wins exactly where the tuned tile's remainder is
+// small: one to four 1080p pairs, levels 3-4: -4 .. -18 % per stage; 480 or 920 workgroups: +4 .. +16 % (the tuned tile
+// fits its rounds).  Times in units of a full tuned round; a partial round with `l` of `occ` workgroups per CU takes
+// 0.2 + 0.8 l / occ of a full one; a small-tile round does 1.5x the work of a tuned one at ~8 % less efficiency, times the
+// padded-area ratio of the two tilings.  Fitted to tools/cfg_sweep.py at eight shapes (profiles/r06_tail_rule_sweeps.txt);
+// bf16 direct convs and the >= 256-cout concat convs only (the 64 / 128-cout concat gathers and the fused stem measured
+// slower on the small tile at every size: they interpolate / evaluate their halo twice; fp32 / bf16x2 not measured).
+inline bool small_tile_wins_on_the_tail(long long nblk_big, long long nblk_small, double area_ratio)
+{
+    auto rounds = [](long long n, int slots, int occ) {
+        const long long full = n / slots, rem = n % slots;
+        return (double)full + (rem ? 0.2 + 0.8 * (double)((rem + 255) / 256) / occ : 0.0);
+    };
+    return rounds(nblk_small, 768, 3) * 0.81 * area_ratio < rounds(nblk_big, 512, 2);
+}
+
 inline ConvCfg choose_conv_cfg(bool fp32, bool x2, int B, int H, int W, int Cin, int Cout, bool splittable,
-                               int force_small = -1, int force_ksplit = 0, bool concat = false, bool kwave_ok = false)
+                               int force_small = -1, int force_ksplit = 0, bool concat = false, bool kwave_ok = false,
+                               bool tail_rule_ok = false)
 {
     const int PL = fp32 ? 16 : 32;
     const int nplanes = Cin / PL * (x2 ? 3 : 1);
     const TileShape big = big_tile(H, W, Cout);
     const long long nblk_big = tile_blocks(big, B, H, W, Cout), nblk_small = tile_blocks(kSmallTile, B, H, W, Cout);
-    // the chip is full with the tuned tile: whole K loop, nothing to choose
-    if (nblk_big >= 256 && force_small < 0 && force_ksplit <= 0) return ConvCfg{false, 1};
+    // the chip is full with the tuned tile: whole K loop; the tile by the partial-round rule up to a few rounds, tuned beyond
+    if (nblk_big >= 256 && force_small < 0 && force_ksplit <= 0) {
+        const bool small = tail_rule_ok && !fp32 && !x2 && nblk_big <= 2304 &&
+                           small_tile_wins_on_the_tail(nblk_big, nblk_small,
+                                                       (double)padded_area(H, W, kSmallTile.TH, kSmallTile.TW) /
+                                                           (double)padded_area(H, W, big.TH, big.TW));
+        return ConvCfg{small, 1};
+    }
     const bool may_split = splittable && nblk_big < (nblk_big / B < 64 ? 256 : 128);
     // bf16, direct sources, >= 4 planes of K, at most one workgroup per CU: the K loop cut over the WAVES of a workgroup
     // (conv3x3_kwave.hip.h) - a quarter of the serial step chain with no slab and no reduction dispatch (kwave_applies).
@@ -578,7 +603,8 @@ template <typename T, int MODE, int EPI> int launch_conv_shape(const ConvArgs& a
     constexpr bool kwave_kind = sizeof(T) == 2 && (MODE == SRC_DIRECT || MODE == SRC_DIRECT_X2) && (EPI == EPI_PLAIN || EPI == EPI_POOL);
     const ConvCfg cfg = choose_conv_cfg(sizeof(T) == 4, src_is_x2(MODE), a.B, a.H, a.W, a.C0 + a.C1, a.Cout,
                                         splittable_kind && a.kslab && a.dst, a.force_tile - 1, a.force_ksplit,
-                                        MODE == SRC_CONCAT_UP, kwave_kind);
+                                        MODE == SRC_CONCAT_UP, kwave_kind,
+                                        sizeof(T) == 2 && (MODE == SRC_DIRECT || (MODE == SRC_CONCAT_UP && a.Cout >= 256)));
     if constexpr (kwave_kind) {
         if (cfg.kwave) return launch_kwave<EPI, MODE == SRC_DIRECT_X2>(a, s);
     }
@@ -1547,7 +1573,7 @@ int fiunet_debug_choose_cfg(int precision, int B, int H, int W, int Cin, int Cou
         (precision != FIUNET_FP32 && precision != FIUNET_BF16 && precision != FIUNET_BF16X2))
         return fail(FIUNET_ERR_INVALID_ARG, "fiunet_debug_choose_cfg: bad arguments");
     const ConvCfg c = choose_conv_cfg(precision == FIUNET_FP32, precision == FIUNET_BF16X2, B, H, W, Cin, Cout, splittable != 0,
-                                      -1, 0, concat_stage != 0, kwave_ok != 0);
+                                      -1, 0, concat_stage != 0, kwave_ok != 0, kwave_ok != 0 && precision == FIUNET_BF16);
     out[0] = c.small; out[1] = c.ksplit; out[2] = c.kwave;
     out[3] = concat_stage >= 10 && concat_stage < NCONV && kMode[concat_stage] == SRC_CONCAT_UP
                  ? materialise_up(concat_stage, precision, false, B, H, W) : 0;

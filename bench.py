@@ -617,12 +617,6 @@ def main():
         elapsed = float(t.item())
     default_workload = (b, h, w, args.precision, args.unfused) == (8, 1080, 1920, "bf16", False)
     power = None
-    if world == 1 and default_workload and not args.no_power:
-        try:
-            power = power_leg(model, f1, f2, dev)
-        except Exception as e:  # an extra leg must never cost the headline line
-            power = {"error": f"{type(e).__name__}: {e}"}
-    del f1, f2
 
     # ---- config 4 / config 5 legs (every rank takes part; bounded, failures are reported) ----
     n_video = args.video_frames if args.video_frames >= 0 else (3000 if default_workload else 0)
@@ -655,6 +649,16 @@ def main():
                                               video_res, tile_res, None, None)))
                     sys.stdout.flush()
                 os._exit(3)
+
+    # (after the config-4 / config-5 legs since round 6: four seconds of back-to-back forwards right before the 5.7-s video
+    # leg heat-soaked the chip it was then compared on - on a warm box the video rate read 3-4 % under `value` while the
+    # host-resident variant, which starts after seconds of host-side staging, did not)
+    if world == 1 and default_workload and not args.no_power:
+        try:
+            power = power_leg(model, f1, f2, dev)
+        except Exception as e:  # an extra leg must never cost the headline line
+            power = {"error": f"{type(e).__name__}: {e}"}
+    del f1, f2
 
     if rank != 0:
         if dist is not None:

@@ -556,7 +556,7 @@ def test_convtranspose_variant_per_layer_golden_fixture(convt_model, dev, golden
 # ---- round 6: the small-problem configuration (tile family, K cut) -----------------------------------------------------
 @pytest.mark.parametrize("prec", ["fp32", "bf16", "bf16x2"])
 def test_tile_family_never_changes_a_bit(model, dev, prec):
-    """The small tile (64 couts x 8x32 pixels, 64 x 64 wave tiles, 4-deep weight ring, its own fused-stem and fused-head
+    """The small tile (64 couts x 8x32 pixels, 64 x 64 wave tiles, three workgroups per CU, its own fused-stem and fused-head
     forms) against the tuned tiles on the same K cut: bit-identical on every stage - the summation order of an output
     element is (plane, kx, ky) in every tile shape and the fused head reduces in the same association.  Sizes: one that
     the default configuration runs on small tiles (64x96) and one it runs on tuned tiles (2 x 270x480), each forced
