@@ -1,32 +1,30 @@
-"""A/B builds of libfiunet_hip.so in precision bf16x2 on ONE box: interleaved rounds, separate processes.
-usage: python tools/ab_x2.py name=path.so ... [--rounds 3] [--shape B H W] (path `default` = the in-tree library)"""
-import os, re, statistics, subprocess, sys
+"""A/B of two libraries on the bf16x2 legs (same box, separate processes, interleaved): python tools/ab_x2.py libA.so libB.so [rounds]"""
+import json, os, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-libs = [a.split("=", 1) for a in sys.argv[1:] if "=" in a]
-rounds = int(sys.argv[sys.argv.index("--rounds") + 1]) if "--rounds" in sys.argv else 3
-shape = sys.argv[sys.argv.index("--shape") + 1:sys.argv.index("--shape") + 4] if "--shape" in sys.argv else ["4", "1080", "1920"]
-prec = sys.argv[sys.argv.index("--precision") + 1] if "--precision" in sys.argv else "bf16x2"
-fps = {n: [] for n, _ in libs}
-last = {}
+libs = sys.argv[1:3]
+rounds = int(sys.argv[3]) if len(sys.argv) > 3 else 2
+code = r'''
+import os, sys, json, torch
+sys.path.insert(0, os.environ["FIUNET_ROOT"])
+import bench
+dev = torch.device("cuda:0")
+m = bench.make_bench_model("bf16x2").to(dev).eval()
+out = {}
+for key, b, h, w, warm, steps in (("b4_1080p", 4, 1080, 1920, 3, 20), ("b8_1080p", 8, 1080, 1920, 2, 10), ("b16_256", 16, 256, 256, 10, 50), ("b1_1080p", 1, 1080, 1920, 10, 60)):
+    g = torch.Generator(device=dev).manual_seed(1)
+    f1 = torch.rand(b, 1, h, w, device=dev, generator=g) * 2 - 1; f2 = torch.rand(b, 1, h, w, device=dev, generator=g) * 2 - 1
+    for _ in range(warm): m(f1, f2)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize(); e0.record()
+    for _ in range(steps): m(f1, f2)
+    e1.record(); torch.cuda.synchronize()
+    out[key] = round(b / (e0.elapsed_time(e1) / steps * 1e-3), 1)
+print(json.dumps(out))
+'''
 for r in range(rounds):
-    for n, p in libs:
-        env = dict(os.environ)
-        if p != "default":
-            env["FIUNET_LIB"] = os.path.join(ROOT, p)
-        run = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "stage_times.py"), *shape, prec, "1", "8"],
-                             env=env, capture_output=True, text=True)
-        out = run.stdout
-        if run.returncode != 0 or "core dump" in (run.stdout + run.stderr).lower():
-            print(n, "FAILED rc", run.returncode, (run.stdout + run.stderr)[-400:]); sys.exit(1)
-        m = re.search(r"([\d.]+) frames/s", out)
-        if not m:   # a failed arm (possibly a GPU fault): stop at once, never launch another GPU process after it
-            print(n, "FAILED", out[-300:]); sys.exit(1)
-        fps[n].append(float(m.group(1))); last[n] = out
-        print(f"round {r} {n}: {m.group(1)} frames/s", flush=True)
-for n in fps:
-    if fps[n]:
-        print(f"{n:16s} median {statistics.median(fps[n]):.1f} min {min(fps[n]):.1f} max {max(fps[n]):.1f}")
-rows = {n: [l for l in last[n].splitlines() if " ms " in l and "TFLOP/s" in l] for n in last}
-names = list(rows)
-for i in range(min(len(v) for v in rows.values()) if rows else 0):
-    print("  " + " | ".join(rows[n][i].split("TFLOP/s")[0].strip() for n in names) + "  " + rows[names[-1]][i].split("TFLOP/s")[1].strip())
+    for lib in libs:
+        env = dict(os.environ, FIUNET_ROOT=ROOT)
+        if lib != "default": env["FIUNET_LIB"] = os.path.join(ROOT, lib)
+        res = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True)
+        line = [l for l in res.stdout.splitlines() if l.startswith("{")]
+        print(f"round {r} {lib}: {line[-1] if line else 'FAILED ' + res.stderr[-300:]}", flush=True)
