@@ -449,7 +449,7 @@ inline bool kwave_applies(int B, int H, int W, int Cin, int Cout)
 // padded-area ratio of the two tilings.  Fitted to tools/cfg_sweep.py at eight shapes (profiles/r06_tail_rule_sweeps.txt);
 // bf16 direct convs and the >= 256-cout concat convs only (the 64 / 128-cout concat gathers and the fused stem measured
 // slower on the small tile at every size: they interpolate / evaluate their halo twice); bf16x2's direct convs follow the
-// same rule (A/B: B = 4 1080p 183.2 -> 185.3 frames/s, B = 1 169 -> 178); fp32 not measured.
+// same rule (A/B: B = 4 1080p 183.2 -> 185.3 frames/s, B = 1 169 -> 178), and so does fp32 (B = 4 53.2 -> 53.9, B = 1 47.5 -> 50.3).
 inline bool small_tile_wins_on_the_tail(long long nblk_big, long long nblk_small, double area_ratio)
 {
     auto rounds = [](long long n, int slots, int occ) {
@@ -469,7 +469,7 @@ inline ConvCfg choose_conv_cfg(bool fp32, bool x2, int B, int H, int W, int Cin,
     const long long nblk_big = tile_blocks(big, B, H, W, Cout), nblk_small = tile_blocks(kSmallTile, B, H, W, Cout);
     // the chip is full with the tuned tile: whole K loop; the tile by the partial-round rule up to a few rounds, tuned beyond
     if (nblk_big >= 256 && force_small < 0 && force_ksplit <= 0) {
-        const bool small = tail_rule_ok && !fp32 && nblk_big <= 2304 &&
+        const bool small = tail_rule_ok && nblk_big <= 2304 &&
                            small_tile_wins_on_the_tail(nblk_big, nblk_small,
                                                        (double)padded_area(H, W, kSmallTile.TH, kSmallTile.TW) /
                                                            (double)padded_area(H, W, big.TH, big.TW));
@@ -605,7 +605,7 @@ template <typename T, int MODE, int EPI> int launch_conv_shape(const ConvArgs& a
     const ConvCfg cfg = choose_conv_cfg(sizeof(T) == 4, src_is_x2(MODE), a.B, a.H, a.W, a.C0 + a.C1, a.Cout,
                                         splittable_kind && a.kslab && a.dst, a.force_tile - 1, a.force_ksplit,
                                         MODE == SRC_CONCAT_UP, kwave_kind,
-                                        sizeof(T) == 2 && (MODE == SRC_DIRECT || MODE == SRC_DIRECT_X2 || (MODE == SRC_CONCAT_UP && a.Cout >= 256)));
+                                        (MODE == SRC_DIRECT || MODE == SRC_DIRECT_X2 || (MODE == SRC_CONCAT_UP && a.Cout >= 256)));
     if constexpr (kwave_kind) {
         if (cfg.kwave) return launch_kwave<EPI, MODE == SRC_DIRECT_X2>(a, s);
     }
@@ -1574,7 +1574,7 @@ int fiunet_debug_choose_cfg(int precision, int B, int H, int W, int Cin, int Cou
         (precision != FIUNET_FP32 && precision != FIUNET_BF16 && precision != FIUNET_BF16X2))
         return fail(FIUNET_ERR_INVALID_ARG, "fiunet_debug_choose_cfg: bad arguments");
     const ConvCfg c = choose_conv_cfg(precision == FIUNET_FP32, precision == FIUNET_BF16X2, B, H, W, Cin, Cout, splittable != 0,
-                                      -1, 0, concat_stage != 0, kwave_ok != 0, kwave_ok != 0 && precision != FIUNET_FP32);
+                                      -1, 0, concat_stage != 0, kwave_ok != 0 && precision != FIUNET_FP32, kwave_ok != 0);
     out[0] = c.small; out[1] = c.ksplit; out[2] = c.kwave;
     out[3] = concat_stage >= 10 && concat_stage < NCONV && kMode[concat_stage] == SRC_CONCAT_UP
                  ? materialise_up(concat_stage, precision, false, B, H, W) : 0;

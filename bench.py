@@ -603,12 +603,18 @@ def main():
     for _ in range(args.warmup):
         model(f1, f2)
     model._ctx.profile_read()
+    # (no garbage-collector pause inside the timed region: a step is 18 asynchronous launches the host must stay ahead of;
+    # one run of round 6 lost 19 ms in ONE stage of ONE of its 20 steps - launch starvation, the kernels were not slower)
+    import gc
+    gc.collect()
+    gc.disable()
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         model(f1, f2)
     barrier()
     elapsed = time.perf_counter() - t0
+    gc.enable()
     nfw, rows = model._ctx.profile_read()
     model._ctx.profile_enable(False)
     if dist is not None:

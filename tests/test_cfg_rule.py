@@ -2,7 +2,7 @@
 workgroups, K cut over the waves of a workgroup) through the diagnostic entry point `fiunet_debug_choose_cfg` - pure host
 arithmetic, no device call.  What is pinned here is what callers rely on:
   * a problem that fills the chip keeps the whole K loop, and the tuned tiles except where their last partial round of
-    workgroups would cost a whole one (bf16 / bf16x2 direct convs, levels 3-4 of one to four 1080p pairs, level 4 at eight);
+    workgroups would cost a whole one (direct convs, levels 3-4 of one to four 1080p pairs, level 4 at eight);
   * a pair's K cuts never depend on the batch for frames of >= 1080p (bitwise batch invariance, include/fiunet.h);
   * ONE 256x256 pair - the reference's own operating point, /root/reference/model/inference.py:29,101-122 - takes the small
     tile on every layer, the in-workgroup cut on the direct convs with >= 4 planes in bf16, never in fp32;
@@ -45,15 +45,15 @@ def test_1080p_never_cuts_k_and_tiles_follow_the_round_count(choose, prec):
     hs, ws = _levels(1080, 1920)
     for b in (1, 2, 3, 4, 8, 16):
         for cin, cout, lv, cs in CONVS:
-            c = choose(prec, b, hs[lv], ws[lv], cin, cout, concat_stage=cs, kwave_ok=cs == 0)
+            c = choose(prec, b, hs[lv], ws[lv], cin, cout, concat_stage=cs, kwave_ok=cs == 0)   # (kwave_ok = a direct launch)
             assert c["ksplit"] == 1 and not c["kwave"], (prec, b, cin, cout, lv, c)     # bitwise batch invariance from B = 1
             # the tile never changes a bit, so it may follow the workgroup count: tuned tiles wherever the chip is full,
-            # except (bf16 / bf16x2 direct convs) where the tuned tile's last, partial round of workgroups would cost a whole one
-            if b >= 2 and (prec == FP32 or lv <= 2 or cs):
+            # except (direct convs) where the tuned tile's last, partial round of workgroups would cost a whole one
+            if b >= 2 and (lv <= 2 or cs):
                 assert not c["small"], (prec, b, cin, cout, lv, c)
-            if prec != FP32 and b == 8 and lv == 4:
+            if b == 8 and lv == 4:
                 assert c["small"], (b, cin, cout, lv, c)      # 1 152 tuned workgroups = 2.25 rounds; 2 304 small ones = 3 full rounds
-            if prec != FP32 and b == 1 and lv == 3 and not cs and cout == 512:
+            if b == 1 and lv == 3 and not cs and cout == 512:
                 assert c["small"], (b, cin, cout, lv, c)      # 544 tuned workgroups on 512 slots
 
 
