@@ -409,7 +409,7 @@ inline long long tile_blocks(const TileShape& t, int B, int H, int W, int Cout)
 //  * never more workgroups than 512 (bf16) / 256 (fp32) in total, never a slab beyond kSlabBytes.
 inline int pow2_floor(long long v) { int k = 1; while (2LL * k <= v) k *= 2; return k; }
 
-inline int small_ksplit(bool fp32, long long nblk, int nplanes, bool concat)
+inline int small_ksplit(bool fp32, long long nblk, int nplanes)
 {
     int k;
     if (nblk >= 256) return 1;   // one workgroup per CU already: a cut only adds the slab (B = 16 256x256, level 4: 39.3 -> 42.9 us)
@@ -418,7 +418,6 @@ inline int small_ksplit(bool fp32, long long nblk, int nplanes, bool concat)
         k = nplanes < 8 ? 1 : (nplanes < 16 ? 4 : 8);
         k = std::min(k, pow2_floor(std::max<long long>(1, 512 / std::max<long long>(nblk, 1))));
     }
-    (void)concat;
     k = std::min(k, pow2_floor(nplanes));
     while (k > 1 && (size_t)k * nblk * kSmallTile.BN * kSmallTile.TH * kSmallTile.TW * 4 > kSlabBytes) k /= 2;
     return k;
@@ -460,8 +459,7 @@ inline bool small_tile_wins_on_the_tail(long long nblk_big, long long nblk_small
 }
 
 inline ConvCfg choose_conv_cfg(bool fp32, bool x2, int B, int H, int W, int Cin, int Cout, bool splittable,
-                               int force_small = -1, int force_ksplit = 0, bool concat = false, bool kwave_ok = false,
-                               bool tail_rule_ok = false)
+                               int force_small = -1, int force_ksplit = 0, bool kwave_ok = false, bool tail_rule_ok = false)
 {
     const int PL = fp32 ? 16 : 32;
     const int nplanes = Cin / PL * (x2 ? 3 : 1);
@@ -499,7 +497,7 @@ inline ConvCfg choose_conv_cfg(bool fp32, bool x2, int B, int H, int W, int Cin,
             const long long nwg = nblk * k;
             return (double)((nwg + 255) / 256) * ((nplanes + k - 1) / k * 3) * step_ns + (k > 1 ? 8000.0 : 0.0);
         };
-        const int ks = may_split ? small_ksplit(true, nblk_small, nplanes, concat) : 1, kb = may_split ? big_ksplit() : 1;
+        const int ks = may_split ? small_ksplit(true, nblk_small, nplanes) : 1, kb = may_split ? big_ksplit() : 1;
         small = mfma_ns(nblk_small, ks, 2950.0) <= mfma_ns(nblk_big, kb, 5900.0);
     }
     const TileShape& t = small ? kSmallTile : big;
@@ -509,7 +507,7 @@ inline ConvCfg choose_conv_cfg(bool fp32, bool x2, int B, int H, int W, int Cin,
         k = splittable ? std::min(pow2_floor(force_ksplit), pow2_floor(nplanes)) : 1;
         while (k > 1 && (size_t)k * nblk * t.BN * t.TH * t.TW * 4 > kSlabBytes) k /= 2;
     } else if (may_split) {
-        k = small ? small_ksplit(fp32, nblk, nplanes, concat) : big_ksplit();
+        k = small ? small_ksplit(fp32, nblk, nplanes) : big_ksplit();
     }
     return ConvCfg{small, k};
 }
@@ -603,8 +601,7 @@ template <typename T, int MODE, int EPI> int launch_conv_shape(const ConvArgs& a
     if ((EPI == EPI_HEAD || EPI == EPI_HEAD3) && a.Cout != 64) return fail(FIUNET_ERR_INVALID_ARG, "fused head needs Cout == 64");
     constexpr bool kwave_kind = sizeof(T) == 2 && (MODE == SRC_DIRECT || MODE == SRC_DIRECT_X2) && (EPI == EPI_PLAIN || EPI == EPI_POOL);
     const ConvCfg cfg = choose_conv_cfg(sizeof(T) == 4, src_is_x2(MODE), a.B, a.H, a.W, a.C0 + a.C1, a.Cout,
-                                        splittable_kind && a.kslab && a.dst, a.force_tile - 1, a.force_ksplit,
-                                        MODE == SRC_CONCAT_UP, kwave_kind,
+                                        splittable_kind && a.kslab && a.dst, a.force_tile - 1, a.force_ksplit, kwave_kind,
                                         (MODE == SRC_DIRECT || MODE == SRC_DIRECT_X2 || (MODE == SRC_CONCAT_UP && a.Cout >= 256)));
     if constexpr (kwave_kind) {
         if (cfg.kwave) return launch_kwave<EPI, MODE == SRC_DIRECT_X2>(a, s);
@@ -1263,7 +1260,6 @@ int fiunet_min_unsplit_batch(const fiunet_ctx* ctx, int H, int W, int precision)
             if (i == 1 && po.fused_stem) continue;            // SRC_STEM launches are never cut
             const ConvCfg c = choose_conv_cfg(precision == FIUNET_FP32, precision == FIUNET_BF16X2, B, hs[kLevel[i]], ws[kLevel[i]],
                                               ctx->conv[i].cin, ctx->cout[i], true, ctx->force_tile[i] - 1, ctx->force_ksplit[i],
-                                              kMode[i] == SRC_CONCAT_UP,
                                               precision != FIUNET_FP32 &&
                                                   (kMode[i] != SRC_CONCAT_UP || po.unfused ||
                                                    materialise_up(i, precision, po.unfused || po.gather_up, B, hs[kLevel[i]], ws[kLevel[i]], ctx->cout, po.convt)));
@@ -1574,7 +1570,7 @@ int fiunet_debug_choose_cfg(int precision, int B, int H, int W, int Cin, int Cou
         (precision != FIUNET_FP32 && precision != FIUNET_BF16 && precision != FIUNET_BF16X2))
         return fail(FIUNET_ERR_INVALID_ARG, "fiunet_debug_choose_cfg: bad arguments");
     const ConvCfg c = choose_conv_cfg(precision == FIUNET_FP32, precision == FIUNET_BF16X2, B, H, W, Cin, Cout, splittable != 0,
-                                      -1, 0, concat_stage != 0, kwave_ok != 0 && precision != FIUNET_FP32, kwave_ok != 0);
+                                      -1, 0, kwave_ok != 0 && precision != FIUNET_FP32, kwave_ok != 0);
     out[0] = c.small; out[1] = c.ksplit; out[2] = c.kwave;
     out[3] = concat_stage >= 10 && concat_stage < NCONV && kMode[concat_stage] == SRC_CONCAT_UP
                  ? materialise_up(concat_stage, precision, false, B, H, W) : 0;
