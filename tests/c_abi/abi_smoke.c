@@ -101,6 +101,35 @@ int main(int argc, char** argv)
         fclose(o);
         HK(hipFree(ws));
     }
+    /* the uint8 video entry points: the strided form (ABI v5: every second frame of an interleaved stack) must write the
+     * same bytes as the contiguous one, and nothing in between */
+    {
+        const size_t img = (size_t)H * W, wsb = fiunet_workspace_bytes_u8(ctx, B, H, W, FIUNET_FP32);
+        unsigned char *hu = (unsigned char*)malloc(npx), *ha = (unsigned char*)malloc(npx), *hb = (unsigned char*)malloc(2 * npx);
+        unsigned char *u1, *u2, *ua, *ub;
+        void* ws = NULL;
+        if (!wsb || !hu || !ha || !hb) return 11;
+        for (size_t i = 0; i < npx; ++i) hu[i] = (unsigned char)((i * 37 + (i >> 7) * 11) & 255);
+        HK(hipMalloc((void**)&u1, npx)); HK(hipMalloc((void**)&u2, npx)); HK(hipMalloc((void**)&ua, npx)); HK(hipMalloc((void**)&ub, 2 * npx));
+        HK(hipMalloc(&ws, wsb));
+        HK(hipMemcpy(u1, hu, npx, hipMemcpyHostToDevice));
+        for (size_t i = 0; i < npx; ++i) hu[i] = (unsigned char)(255 - hu[i]);
+        HK(hipMemcpy(u2, hu, npx, hipMemcpyHostToDevice));
+        HK(hipMemset(ub, 7, 2 * npx));
+        CK(fiunet_forward_u8(ctx, u1, u2, ua, B, H, W, FIUNET_FP32, ws, wsb, (void*)stream));
+        CK(fiunet_forward_u8_strided(ctx, u1, u2, ub + img, 2 * img, B, H, W, FIUNET_FP32, ws, wsb, (void*)stream));
+        if (fiunet_forward_u8_strided(ctx, u1, u2, ub, img - 1, B, H, W, FIUNET_FP32, ws, wsb, (void*)stream) != FIUNET_ERR_INVALID_ARG) return 12;
+        HK(hipStreamSynchronize(stream));
+        HK(hipMemcpy(ha, ua, npx, hipMemcpyDeviceToHost));
+        HK(hipMemcpy(hb, ub, 2 * npx, hipMemcpyDeviceToHost));
+        for (int b = 0; b < B; ++b)
+            for (size_t i = 0; i < img; ++i) {
+                if (hb[(2 * b + 1) * img + i] != ha[b * img + i]) return 13;   /* the interpolated frames, in place */
+                if (hb[(2 * b) * img + i] != 7) return 14;                      /* the frames in between: untouched */
+            }
+        HK(hipFree(u1)); HK(hipFree(u2)); HK(hipFree(ua)); HK(hipFree(ub)); HK(hipFree(ws));
+        free(hu); free(ha); free(hb);
+    }
     CK(fiunet_destroy(ctx));
     printf("abi_smoke ok B=%d H=%d W=%d\n", B, H, W);
     return 0;
