@@ -1,7 +1,7 @@
 // conv3x3_kwave.hip.h -- the fused 3x3 conv of conv3x3_mfma.hip.h for SMALL problems with a long K loop, with the K
 // loop cut INSIDE the workgroup: the four waves of a workgroup work on the SAME 64 couts x 2x32 pixels, each on its own
 // quarter of the input planes, against its own private in-tile and weight ring in LDS, and meet once, through LDS, at
-// the end.  gfx950 only; bf16 operands (precisions "bf16" and "bf16x2").
+// the end.  gfx950 only; all three precisions.
 //
 // Why (round 6): the reference itself only ever forwards ONE 256x256 pair
 // (/root/reference/model/inference.py:29,101-122).  At that size a deep layer has 4-64 tiles and 8-32 planes of K; a lone
@@ -13,7 +13,7 @@
 // dispatch and no barrier inside the K loop at all: a wave's LDS traffic is private, so its only synchronisation is its
 // own `s_waitcnt`.
 //
-// Same arithmetic per product as conv3x3_mfma_kernel (bf16 MFMA, fp32 accumulation, BatchNorm scale in the weights and
+// Same arithmetic per product as conv3x3_mfma_kernel (the element type's MFMA, fp32 accumulation, BatchNorm scale in the weights and
 // shift in the accumulators' start value, the same epilogue code incl. the fused MaxPool2d(2) copy); the fp32 SUMMATION
 // ORDER of an output element is that of a 4-way K cut: ((q0 + q1) + q2) + q3 over the plane quarters, planes / kx / ky in
 // order inside a quarter.  Deterministic; independent of the batch and of the position in the batch.
@@ -41,12 +41,15 @@ struct KWaveTile {
 // X2: precision "bf16x2" (SRC_DIRECT_X2 of conv3x3_mfma.hip.h): two-piece activations [hi planes | lo planes] and weights
 // [wh | wl]; a wave's quarter is a range of REAL planes, each run as three virtual planes - (xh, wh), (xh, wl) on the same
 // in-tile, (xl, wh) - and the epilogue writes the two pieces of the output.
-template <int EPI, bool X2 = false>
+// T: __bf16 (precisions "bf16" / "bf16x2") or float (the exact-fp32 path: same 64-B plane records and LDS images, 16
+// channels per plane, four fp32 MFMAs per fragment pair - there a step is MFMA time, so the kernel is chosen where it keeps
+// every SIMD of the chip busy, i.e. from 256 workgroups x 4 waves on, and what it saves is the slab and the reduce dispatch).
+template <int EPI, bool X2 = false, typename T = __bf16>
 __global__ __launch_bounds__(256, 1) void conv3x3_kwave_kernel(const ConvArgs a)
 {
-    using T = __bf16;
     using Tile = KWaveTile;
-    constexpr int PL = 32;
+    constexpr int PL = Elem<T>::PL;
+    static_assert(!X2 || sizeof(T) == 2, "two-piece operands are bf16");
     constexpr int TWP = Tile::TWP, THP = Tile::THP, TW = Tile::TW, TH = Tile::TH, BN = Tile::BN;
     constexpr int FR = 2, NF = 4, ROWS_W = 2;
     static_assert(EPI == EPI_PLAIN || EPI == EPI_POOL, "plain or pooled epilogue");

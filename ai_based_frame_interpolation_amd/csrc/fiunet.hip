@@ -405,15 +405,18 @@ inline long long tile_blocks(const TileShape& t, int B, int H, int W, int Cout)
 //    (k slices of the padded fp32 output written, then read back through the Infinity Cache at ~2.5-4.5 TB/s): cutting
 //    pays from 8 planes (24 serial steps) on, best at 2-4 planes per slice - k = 4 for 8 planes, 8 beyond;
 //  * fp32: a step is MFMA time (~3 us per 64 x 64 wave tile), so what counts is one workgroup on every CU: k = 256 /
-//    workgroups (a second workgroup per CU shares the same MFMA pipes: no gain, twice the slab);
+//    workgroups (a second workgroup per CU shares the same MFMA pipes: no gain, twice the slab) - except the concat convs,
+//    whose gather interpolates its upsampled half (address arithmetic and blend per tap, latency- not MFMA-bound): two
+//    workgroups per CU hide it, k = 512 / workgroups (ONE 256x256 pair, up1.0 / up2.0 / up3.0: 98 -> 92-95 us; four pairs,
+//    up1.0: 335 -> 304 us; profiles/r06_cfg_sweep_b{1,4}_256_fp32.txt);
 //  * never more workgroups than 512 (bf16) / 256 (fp32) in total, never a slab beyond kSlabBytes.
 inline int pow2_floor(long long v) { int k = 1; while (2LL * k <= v) k *= 2; return k; }
 
-inline int small_ksplit(bool fp32, long long nblk, int nplanes)
+inline int small_ksplit(bool fp32, long long nblk, int nplanes, int fp32_slots = 256)
 {
     int k;
-    if (nblk >= 256) return 1;   // one workgroup per CU already: a cut only adds the slab (B = 16 256x256, level 4: 39.3 -> 42.9 us)
-    if (fp32) k = pow2_floor(std::max<long long>(1, 256 / std::max<long long>(nblk, 1)));
+    if (nblk >= (fp32 ? fp32_slots : 256)) return 1;   // the chip is covered already: a cut only adds the slab (B = 16 256x256, level 4: 39.3 -> 42.9 us)
+    if (fp32) k = pow2_floor(std::max<long long>(1, fp32_slots / std::max<long long>(nblk, 1)));
     else {
         k = nplanes < 8 ? 1 : (nplanes < 16 ? 4 : 8);
         k = std::min(k, pow2_floor(std::max<long long>(1, 512 / std::max<long long>(nblk, 1))));
@@ -459,7 +462,8 @@ inline bool small_tile_wins_on_the_tail(long long nblk_big, long long nblk_small
 }
 
 inline ConvCfg choose_conv_cfg(bool fp32, bool x2, int B, int H, int W, int Cin, int Cout, bool splittable,
-                               int force_small = -1, int force_ksplit = 0, bool kwave_ok = false, bool tail_rule_ok = false)
+                               int force_small = -1, int force_ksplit = 0, bool kwave_ok = false, bool tail_rule_ok = false,
+                               bool concat_conv = false)
 {
     const int PL = fp32 ? 16 : 32;
     const int nplanes = Cin / PL * (x2 ? 3 : 1);
@@ -478,6 +482,7 @@ inline ConvCfg choose_conv_cfg(bool fp32, bool x2, int B, int H, int W, int Cin,
     // (conv3x3_kwave.hip.h) - a quarter of the serial step chain with no slab and no reduction dispatch (kwave_applies).
     // (bf16x2 runs nine steps per real plane: from 16 planes on its per-wave chain is longer than what a cross-workgroup cut
     // of 8 leaves - ONE 256x256 pair, down4: 34 us against 26 - so there the slab form stays; profiles/r06_cfg_sweep_b1_256_bf16x2.txt)
+    if (kwave_ok && fp32 && splittable && Cin / 16 >= 4 && force_small == 2) return ConvCfg{true, 1, true};
     if (kwave_ok && !fp32 && splittable && Cin / 32 >= 4 && (force_small == 2 || (force_small < 0 && force_ksplit <= 0))) {
         if (force_small == 2 || (kwave_applies(B, H, W, Cin, Cout) && !(x2 && Cin / 32 > 8))) return ConvCfg{true, 1, true};
     }
@@ -493,12 +498,23 @@ inline ConvCfg choose_conv_cfg(bool fp32, bool x2, int B, int H, int W, int Cin,
         // fp32 is MFMA-bound per SIMD: where the 8x32 tile pads a narrow level (16 columns: half of every tile is
         // padding) AND the batch already fills the chip, the tuned 16x16 tile with its K cut does half the MFMAs
         // (B = 16 256x256, level 4: 64 tuned workgroups x 4 slices x 24 steps against 256 small ones x 96 steps)
+        const int slots = concat_conv ? 512 : 256;
         auto mfma_ns = [&](long long nblk, int k, double step_ns) {
             const long long nwg = nblk * k;
-            return (double)((nwg + 255) / 256) * ((nplanes + k - 1) / k * 3) * step_ns + (k > 1 ? 8000.0 : 0.0);
+            return (double)((nwg + slots - 1) / slots) * ((nplanes + k - 1) / k * 3) * step_ns + (k > 1 ? 8000.0 : 0.0);
         };
-        const int ks = may_split ? small_ksplit(true, nblk_small, nplanes) : 1, kb = may_split ? big_ksplit() : 1;
+        const int ks = may_split ? small_ksplit(true, nblk_small, nplanes, slots) : 1, kb = may_split ? big_ksplit() : 1;
         small = mfma_ns(nblk_small, ks, 2950.0) <= mfma_ns(nblk_big, kb, 5900.0);
+        // fp32 and the in-workgroup cut (conv3x3_kwave_kernel<.., float>): the same MFMA time per SIMD as a cut over
+        // workgroups when its workgroups x 4 waves cover the chip, without the slab and the reduce dispatch (~8 us).
+        // One workgroup per CU (136 KiB of LDS), up to two rounds of them.  ONE 256x256 pair: down1.0 35.0 -> 31.7 us,
+        // down1.1 56.3 -> 50.9, down2.0 34 -> 28.0, down2.1 57 -> 47.1, up3.1 35 -> 27.3; where the cut over workgroups
+        // reaches one workgroup per CU with fewer steps it stays (down3.0: 35.4 against 43.0) - profiles/r06_cfg_sweep_b{1,4}_256_fp32.txt
+        if (kwave_ok && splittable && may_split && nplanes >= 4 && Cout % 64 == 0) {
+            const long long nwg = (long long)B * ((H + 1) / 2) * ((W + 31) / 32) * (Cout / 64);
+            const double kw = (double)((nwg + 255) / 256) * ((nplanes + 3) / 4 * 3) * 2950.0;
+            if (nwg <= 512 && kw < (small ? mfma_ns(nblk_small, ks, 2950.0) : mfma_ns(nblk_big, kb, 5900.0))) return ConvCfg{true, 1, true};
+        }
     }
     const TileShape& t = small ? kSmallTile : big;
     const long long nblk = small ? nblk_small : nblk_big;
@@ -507,7 +523,7 @@ inline ConvCfg choose_conv_cfg(bool fp32, bool x2, int B, int H, int W, int Cin,
         k = splittable ? std::min(pow2_floor(force_ksplit), pow2_floor(nplanes)) : 1;
         while (k > 1 && (size_t)k * nblk * t.BN * t.TH * t.TW * 4 > kSlabBytes) k /= 2;
     } else if (may_split) {
-        k = small ? small_ksplit(fp32, nblk, nplanes) : big_ksplit();
+        k = small ? small_ksplit(fp32, nblk, nplanes, concat_conv ? 512 : 256) : big_ksplit();
     }
     return ConvCfg{small, k};
 }
@@ -517,12 +533,12 @@ template <typename T, int BN, int TH, int TW, int MODE, int EPI>
 constexpr bool pair_capable() { return MODE == SRC_DIRECT && (EPI == EPI_PLAIN || EPI == EPI_POOL) && BN == 128; }
 
 // The K loop cut over the four waves of a workgroup (small problems, bf16, direct sources): conv3x3_kwave.hip.h.
-template <int EPI, bool X2> int launch_kwave(ConvArgs a, hipStream_t s)
+template <typename T, int EPI, bool X2> int launch_kwave(ConvArgs a, hipStream_t s)
 {
     using Tile = KWaveTile;
     if (g_name_out) {
         char buf[96];
-        std::snprintf(buf, sizeof buf, "conv3x3_kwave_kernel<bf16%s,64,2,32,%d>+kwave4", X2 ? "x2" : "", EPI);
+        std::snprintf(buf, sizeof buf, "conv3x3_kwave_kernel<%s%s,64,2,32,%d>+kwave4", sizeof(T) == 2 ? "bf16" : "f32", X2 ? "x2" : "", EPI);
         *g_name_out = buf;
     }
     a.tilesX = (a.W + Tile::TW - 1) / Tile::TW;
@@ -534,11 +550,11 @@ template <int EPI, bool X2> int launch_kwave(ConvArgs a, hipStream_t s)
     int dev = 0;
     HIP_TRY(hipGetDevice(&dev));
     if (dev >= 0 && dev < 64 && !lds_attr_set[dev].load(std::memory_order_acquire)) {
-        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_kwave_kernel<EPI, X2>),
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_kwave_kernel<EPI, X2, T>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, Tile::LDS_BYTES));
         lds_attr_set[dev].store(true, std::memory_order_release);
     }
-    hipLaunchKernelGGL((conv3x3_kwave_kernel<EPI, X2>), dim3((unsigned)nblk), dim3(256), Tile::LDS_BYTES, s, a);
+    hipLaunchKernelGGL((conv3x3_kwave_kernel<EPI, X2, T>), dim3((unsigned)nblk), dim3(256), Tile::LDS_BYTES, s, a);
     HIP_TRY(hipGetLastError());
     return FIUNET_OK;
 }
@@ -599,12 +615,13 @@ template <typename T, int MODE, int EPI> int launch_conv_shape(const ConvArgs& a
     constexpr bool splittable_kind = !src_is_stem(MODE) && (EPI == EPI_PLAIN || EPI == EPI_POOL);
     if (a.Cout != 64 && a.Cout % 128 != 0) return fail(FIUNET_ERR_INVALID_ARG, "Cout must be 64 or k*128");
     if ((EPI == EPI_HEAD || EPI == EPI_HEAD3) && a.Cout != 64) return fail(FIUNET_ERR_INVALID_ARG, "fused head needs Cout == 64");
-    constexpr bool kwave_kind = sizeof(T) == 2 && (MODE == SRC_DIRECT || MODE == SRC_DIRECT_X2) && (EPI == EPI_PLAIN || EPI == EPI_POOL);
+    constexpr bool kwave_kind = (MODE == SRC_DIRECT || MODE == SRC_DIRECT_X2) && (EPI == EPI_PLAIN || EPI == EPI_POOL);
     const ConvCfg cfg = choose_conv_cfg(sizeof(T) == 4, src_is_x2(MODE), a.B, a.H, a.W, a.C0 + a.C1, a.Cout,
-                                        splittable_kind && a.kslab && a.dst, a.force_tile - 1, a.force_ksplit, kwave_kind,
-                                        (MODE == SRC_DIRECT || MODE == SRC_DIRECT_X2 || (MODE == SRC_CONCAT_UP && a.Cout >= 256)));
+                                        splittable_kind && a.kslab && a.dst, a.force_tile - 1, a.force_ksplit, kwave_kind && !a.concat_origin,
+                                        (MODE == SRC_DIRECT || MODE == SRC_DIRECT_X2 || (MODE == SRC_CONCAT_UP && a.Cout >= 256)),
+                                        MODE == SRC_CONCAT_UP || a.concat_origin);
     if constexpr (kwave_kind) {
-        if (cfg.kwave) return launch_kwave<EPI, MODE == SRC_DIRECT_X2>(a, s);
+        if (cfg.kwave) return launch_kwave<T, EPI, MODE == SRC_DIRECT_X2>(a, s);
     }
     if (cfg.small) return launch_conv_maybe_split<T, 64, 8, 32, MODE, EPI>(a, s, cfg.ksplit);
     if (a.Cout == 64) {
@@ -808,6 +825,7 @@ int forward_impl(fiunet_ctx* ctx, const float* f1, const float* f2, float* out, 
             hipLaunchKernelGGL((upcat_kernel<T>), dim3(grid_for(n)), dim3(256), 0, s, a, scratch);
             HIP_TRY(hipGetLastError());
             a.src0 = scratch; a.C0 = a.C0 + a.C1; a.C1 = 0; a.src1 = nullptr; mode = SRC_DIRECT;
+            if (!bf16) a.concat_origin = 1;
         }
         if (mode == SRC_CONCAT_UP &&
             materialise_up(i, bf16 ? FIUNET_BF16 : FIUNET_FP32, unfused || po.gather_up, B, a.H, a.W, ctx->cout)) {
@@ -1258,11 +1276,12 @@ int fiunet_min_unsplit_batch(const fiunet_ctx* ctx, int H, int W, int precision)
         // the ablation / read-back paths either, so that both accumulate in the same order)
         for (int i = 1; i < NCONV - 1 && !split; ++i) {
             if (i == 1 && po.fused_stem) continue;            // SRC_STEM launches are never cut
+            const bool direct = kMode[i] != SRC_CONCAT_UP || po.unfused ||
+                                materialise_up(i, precision, po.unfused || po.gather_up, B, hs[kLevel[i]], ws[kLevel[i]], ctx->cout, po.convt);
             const ConvCfg c = choose_conv_cfg(precision == FIUNET_FP32, precision == FIUNET_BF16X2, B, hs[kLevel[i]], ws[kLevel[i]],
                                               ctx->conv[i].cin, ctx->cout[i], true, ctx->force_tile[i] - 1, ctx->force_ksplit[i],
-                                              precision != FIUNET_FP32 &&
-                                                  (kMode[i] != SRC_CONCAT_UP || po.unfused ||
-                                                   materialise_up(i, precision, po.unfused || po.gather_up, B, hs[kLevel[i]], ws[kLevel[i]], ctx->cout, po.convt)));
+                                              direct && !(precision == FIUNET_FP32 && kMode[i] == SRC_CONCAT_UP), false,
+                                              kMode[i] == SRC_CONCAT_UP);
             split = c.ksplit > 1 || c.kwave;
         }
         if (!split) return B;
@@ -1569,11 +1588,11 @@ int fiunet_debug_choose_cfg(int precision, int B, int H, int W, int Cin, int Cou
     if (!out || B < 1 || H < 1 || W < 1 || Cin < 32 || (Cout != 64 && Cout % 128 != 0) ||
         (precision != FIUNET_FP32 && precision != FIUNET_BF16 && precision != FIUNET_BF16X2))
         return fail(FIUNET_ERR_INVALID_ARG, "fiunet_debug_choose_cfg: bad arguments");
-    const ConvCfg c = choose_conv_cfg(precision == FIUNET_FP32, precision == FIUNET_BF16X2, B, H, W, Cin, Cout, splittable != 0,
-                                      -1, 0, kwave_ok != 0 && precision != FIUNET_FP32, kwave_ok != 0);
-    out[0] = c.small; out[1] = c.ksplit; out[2] = c.kwave;
     out[3] = concat_stage >= 10 && concat_stage < NCONV && kMode[concat_stage] == SRC_CONCAT_UP
                  ? materialise_up(concat_stage, precision, false, B, H, W) : 0;
+    const ConvCfg c = choose_conv_cfg(precision == FIUNET_FP32, precision == FIUNET_BF16X2, B, H, W, Cin, Cout, splittable != 0,
+                                      -1, 0, kwave_ok != 0, kwave_ok != 0, concat_stage >= 10);
+    out[0] = c.small; out[1] = c.ksplit; out[2] = c.kwave;
     return FIUNET_OK;
 }
 
