@@ -111,9 +111,9 @@ struct ConvArgs {
     int pair;            // host side only: 8-wave tile-pair kernel where it applies (FIUNET_OPT_PAIR_TILES)
     int force_tile;      // host side only (diagnostic, fiunet_debug_force_cfg): 0 = choose, 1 = the big tile, 2 = the small one, 3 = conv3x3_kwave_kernel
     int force_ksplit;    // host side only (diagnostic): 0 = choose, k >= 1 = cut the K loop k ways
-    int concat_origin;   // host side only: 1 = an fp32 concat conv run through upcat_kernel (ablation / read-back path): it takes
-                         // the launch configuration of the fused gather (same K cut, never conv3x3_kwave_kernel), so that
-                         // the two paths stay bit-identical per stage
+    int concat_origin;   // host side only: 1 = an fp32 concat conv run through upcat_kernel (ablation / read-back path) whose fused
+                         // counterpart keeps the in-gather form: it takes that form's launch configuration (same K cut, never
+                         // conv3x3_kwave_kernel), so that the two paths stay bit-identical per stage
     float* kslab;
     unsigned long long* stamp;  // diagnostic builds (-DFIUNET_STAMP / -DFIUNET_CLOCK) only: one 128-B record (16 cycle sums) per wave
     unsigned stamp_cap;         //   records the buffer holds (waves beyond it do not write)

@@ -160,11 +160,14 @@ struct PlanOpts {
 // direct sources only): a quarter of the serial step chain is worth the extra upsample dispatch (ONE 256x256 pair: up1.0
 // 34 -> 23 us, up2.0 30 -> 18 us).  B, H, W: the stage's level.
 inline bool kwave_applies(int B, int H, int W, int Cin, int Cout);
+inline bool fp32_concat_takes_kwave(int B, int H, int W, int Cin, int Cout);
 inline bool materialise_up(int stage, int precision, bool unfused, int B, int H, int W, const int* cout = kCoutBil,
                            bool convt = false)
 {
     if (convt || precision == FIUNET_BF16X2) return kMode[stage] == SRC_CONCAT_UP;   // (no in-gather form for these)
-    if (precision != FIUNET_BF16 || unfused || kMode[stage] != SRC_CONCAT_UP) return false;
+    if (unfused || kMode[stage] != SRC_CONCAT_UP) return false;
+    if (precision == FIUNET_FP32) return fp32_concat_takes_kwave(B, H, W, cout[kSrc0[stage]] + cout[kSrc1[stage]], cout[stage]);
+    if (precision != FIUNET_BF16) return false;
     if (cout[stage] >= 256 && (long long)B * H * W >= 65536) return true;
     return kwave_applies(B, H, W, cout[kSrc0[stage]] + cout[kSrc1[stage]], cout[stage]);
 }
@@ -528,6 +531,14 @@ inline ConvCfg choose_conv_cfg(bool fp32, bool x2, int B, int H, int W, int Cin,
     return ConvCfg{small, k};
 }
 
+// An fp32 concat conv whose direct two-source form would take the in-workgroup K cut: its upsampled half is materialised
+// (upsample_kernel, one more dispatch) and the conv launched in that form - on the ablation path too (upcat_kernel's single
+// source has the same planes in the same order), so the two paths keep the same summation order.
+inline bool fp32_concat_takes_kwave(int B, int H, int W, int Cin, int Cout)
+{
+    return choose_conv_cfg(true, false, B, H, W, Cin, Cout, true, -1, 0, true, false, false).kwave;
+}
+
 // pair kernel: direct sources, plain / pooled epilogue, enough tile pairs to fill the 256 CUs
 template <typename T, int BN, int TH, int TW, int MODE, int EPI>
 constexpr bool pair_capable() { return MODE == SRC_DIRECT && (EPI == EPI_PLAIN || EPI == EPI_POOL) && BN == 128; }
@@ -825,7 +836,7 @@ int forward_impl(fiunet_ctx* ctx, const float* f1, const float* f2, float* out, 
             hipLaunchKernelGGL((upcat_kernel<T>), dim3(grid_for(n)), dim3(256), 0, s, a, scratch);
             HIP_TRY(hipGetLastError());
             a.src0 = scratch; a.C0 = a.C0 + a.C1; a.C1 = 0; a.src1 = nullptr; mode = SRC_DIRECT;
-            if (!bf16) a.concat_origin = 1;
+            if (!bf16 && !fp32_concat_takes_kwave(B, a.H, a.W, a.C0, a.Cout)) a.concat_origin = 1;
         }
         if (mode == SRC_CONCAT_UP &&
             materialise_up(i, bf16 ? FIUNET_BF16 : FIUNET_FP32, unfused || po.gather_up, B, a.H, a.W, ctx->cout)) {
@@ -1278,10 +1289,15 @@ int fiunet_min_unsplit_batch(const fiunet_ctx* ctx, int H, int W, int precision)
             if (i == 1 && po.fused_stem) continue;            // SRC_STEM launches are never cut
             const bool direct = kMode[i] != SRC_CONCAT_UP || po.unfused ||
                                 materialise_up(i, precision, po.unfused || po.gather_up, B, hs[kLevel[i]], ws[kLevel[i]], ctx->cout, po.convt);
+            // fp32 concat convs: the direct form (and its in-workgroup cut) only where fp32_concat_takes_kwave says so and the
+            // options let the upsampled half be a tensor; else the fused gather's configuration, on the ablation path too
+            const bool concat = kMode[i] == SRC_CONCAT_UP;
+            const bool fp32_as_direct = concat && precision == FIUNET_FP32 && direct &&
+                                        fp32_concat_takes_kwave(B, hs[kLevel[i]], ws[kLevel[i]], ctx->conv[i].cin, ctx->cout[i]);
             const ConvCfg c = choose_conv_cfg(precision == FIUNET_FP32, precision == FIUNET_BF16X2, B, hs[kLevel[i]], ws[kLevel[i]],
                                               ctx->conv[i].cin, ctx->cout[i], true, ctx->force_tile[i] - 1, ctx->force_ksplit[i],
-                                              direct && !(precision == FIUNET_FP32 && kMode[i] == SRC_CONCAT_UP), false,
-                                              kMode[i] == SRC_CONCAT_UP);
+                                              precision == FIUNET_FP32 && concat ? fp32_as_direct : direct, false,
+                                              concat && !fp32_as_direct);
             split = c.ksplit > 1 || c.kwave;
         }
         if (!split) return B;
@@ -1590,8 +1606,11 @@ int fiunet_debug_choose_cfg(int precision, int B, int H, int W, int Cin, int Cou
         return fail(FIUNET_ERR_INVALID_ARG, "fiunet_debug_choose_cfg: bad arguments");
     out[3] = concat_stage >= 10 && concat_stage < NCONV && kMode[concat_stage] == SRC_CONCAT_UP
                  ? materialise_up(concat_stage, precision, false, B, H, W) : 0;
+    const bool concat = concat_stage >= 10;
+    const bool tail_rule_ok = kwave_ok != 0;
+    if (concat) kwave_ok = out[3];   // a concat conv has the direct form exactly where its upsampled half is a tensor
     const ConvCfg c = choose_conv_cfg(precision == FIUNET_FP32, precision == FIUNET_BF16X2, B, H, W, Cin, Cout, splittable != 0,
-                                      -1, 0, kwave_ok != 0, kwave_ok != 0, concat_stage >= 10);
+                                      -1, 0, kwave_ok != 0, tail_rule_ok, concat && !(precision == FIUNET_FP32 && out[3]));
     out[0] = c.small; out[1] = c.ksplit; out[2] = c.kwave;
     return FIUNET_OK;
 }

@@ -624,7 +624,7 @@ def test_in_workgroup_k_cut_kernel(model, dev, seeded_sd, prec):
         out = model(d1, d2).clone()
         _, rows = model._ctx.profile_read()
         model._ctx.profile_enable(False)
-        # the direct convs with >= 4 planes (fp32: never a concat conv - its fused gather has no such form)
+        # the direct convs with >= 4 planes
         assert sum("kwave" in r[0] for r in rows) >= 8, [r[0] for r in rows]
         assert torch.equal(out, model(d1, d2))                                       # deterministic
         perm = torch.roll(torch.arange(b), 1).to(dev)
