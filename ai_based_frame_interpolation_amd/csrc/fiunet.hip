@@ -443,7 +443,7 @@ inline bool kwave_applies(int B, int H, int W, int Cin, int Cout)
     return Cin / 32 >= 4 && Cout % 64 == 0 && nwg <= 256;
 }
 
-// kwave_ok: the launch has the form conv3x3_kwave_kernel covers (bf16, direct sources, plain / pooled epilogue).
+// kwave_ok: the launch has the form conv3x3_kwave_kernel covers (direct sources, plain / pooled epilogue; fp32: see below).
 // force_small == 2: that kernel where it applies (diagnostic).
 // Between one and a few ROUNDS of tuned-tile workgroups (512 resident slots) the last, partial round decides: 544
 // workgroups take 1.6 rounds' time (the 32 left over run alone), 480 take one.  The small tile - three workgroups per CU, 768
@@ -543,7 +543,7 @@ inline bool fp32_concat_takes_kwave(int B, int H, int W, int Cin, int Cout)
 template <typename T, int BN, int TH, int TW, int MODE, int EPI>
 constexpr bool pair_capable() { return MODE == SRC_DIRECT && (EPI == EPI_PLAIN || EPI == EPI_POOL) && BN == 128; }
 
-// The K loop cut over the four waves of a workgroup (small problems, bf16, direct sources): conv3x3_kwave.hip.h.
+// The K loop cut over the four waves of a workgroup (small problems, direct sources, every precision): conv3x3_kwave.hip.h.
 template <typename T, int EPI, bool X2> int launch_kwave(ConvArgs a, hipStream_t s)
 {
     using Tile = KWaveTile;
